@@ -1,0 +1,393 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the CogVideoX finetune hot path.
+
+This file is a clean-room CPU restatement, in plain PyTorch (fp32 or fp64, eager, no custom
+kernels), of the arithmetic that the reference's ``CogVideoXWorkFlow.training_step`` executes.
+It exists only so that ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg can check / time the HIP path against it.  Nothing under
+``videotuna-dev_amd/`` may import it.
+
+What it follows (all paths relative to /root/reference, read as text):
+
+* harness math ............ videotuna/models/cogvideo_hf/cogvideo_pl.py:815-887
+                            (add_noise -> DiT -> get_velocity(model_out, noisy, t) -> 1/(1-abar) weights
+                             -> mean over non-batch dims -> mean over batch)
+* AdamW selection ......... cogvideo_pl.py:774-779 (torch.optim.AdamW defaults on requires_grad params)
+* LoRA injection .......... cogvideo_pl.py:143-149 + configs/004_cogvideox/cogvideo2b.yaml:32-38
+                            (peft 0.12.0 LoraConfig r=4 alpha=1 targets to_q,to_k,to_v,to_out.0;
+                             y = W x + b + (alpha/r) * B(A(x)), A kaiming-uniform(a=sqrt 5), B zeros)
+* DiT arithmetic .......... THIRD-PARTY, absent from /root/reference: diffusers==0.32.2
+                            (poetry.lock:1176) ``CogVideoXTransformer3DModel``; restated here from its
+                            published architecture.  In-tree corroboration (SAT
+                            twin): videotuna/models/cogvideo_sat/dit_video_concat.py
+                              - patchify order (c p q), text-first concat ......... :20-56
+                              - 3D sincos pos-embed (1/4 temporal + 3/4 spatial) .. :59-160
+                              - adaLN modulate x*(1+scale)+shift ................. :430-431, 577-666
+                              - qk LayerNorm per head ............................. :554-575, 686-690
+                              - final layer (shift, scale) + unpatchify ........... :442-502
+* noise schedule .......... diffusers ``CogVideoXDPMScheduler`` (absent); in-tree twin
+                            videotuna/models/cogvideo_sat/sgm/modules/diffusionmodules/discretizer.py:80-140
+                            (scaled-linear betas, SNR shift, zero-terminal-SNR) and
+                            videotuna/utils/diffusion_utils.py:36-45
+* timestep sinusoid ....... cos-first, like videotuna/utils/diffusion_utils.py:9-33
+
+PARITY STATUS: the pieces that exist in-tree (pos-embed table, schedule, sinusoid, q_sample/get_v,
+LayerNorm-modulate / MHA / GELU-tanh MLP primitives, LoRA linear) are pinned by golden vectors
+generated from the imported reference modules (tests/golden/make_golden.py).  The composition into
+``CogVideoXTransformer3DModel`` is pinned only by this restatement: the reference holds no test,
+fixture or weight for it and diffusers is not installed -> *whole-model parity unpinned*.
+
+Parameter names are the HF ``diffusion_pytorch_model.safetensors`` keys so a later session that has
+``checkpoints/cogvideo/CogVideoX-2b`` can load real weights into both sides.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# configuration (values of CogVideoX-2b's transformer/config.json)
+# --------------------------------------------------------------------------------------
+@dataclass
+class DiTConfig:
+    num_attention_heads: int = 30
+    attention_head_dim: int = 64
+    in_channels: int = 16
+    out_channels: int = 16
+    num_layers: int = 30
+    time_embed_dim: int = 512
+    text_embed_dim: int = 4096
+    patch_size: int = 2
+    sample_width: int = 90
+    sample_height: int = 60
+    sample_frames: int = 49
+    temporal_compression_ratio: int = 4
+    max_text_seq_length: int = 226
+    spatial_interpolation_scale: float = 1.875
+    temporal_interpolation_scale: float = 1.0
+    norm_eps: float = 1e-5
+    qk_norm_eps: float = 1e-6
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    use_rotary_positional_embeddings: bool = False
+    ff_mult: int = 4
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+def tiny_config(**kw) -> DiTConfig:
+    """A small config with the same structure (used by fixtures / smoke)."""
+    base = dict(num_attention_heads=2, attention_head_dim=64, num_layers=2, time_embed_dim=64,
+                text_embed_dim=64, sample_width=8, sample_height=6, sample_frames=5,
+                max_text_seq_length=10)
+    base.update(kw)
+    return DiTConfig(**base)
+
+
+# --------------------------------------------------------------------------------------
+# tables
+# --------------------------------------------------------------------------------------
+def sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    """[sin, cos] concatenated, sin first (dit_video_concat.py:141-160)."""
+    assert embed_dim % 2 == 0
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_pos_embed_3d(embed_dim: int, grid_h: int, grid_w: int, t_size: int,
+                        spatial_scale: float = 1.0, temporal_scale: float = 1.0) -> np.ndarray:
+    """[T, H*W, D] table: first D/4 temporal, then 3D/4 spatial (w-coordinate half first because
+    ``np.meshgrid(grid_w, grid_h)`` puts w first) -- dit_video_concat.py:59-105,128-137."""
+    assert embed_dim % 4 == 0
+    d_sp = embed_dim // 4 * 3
+    d_t = embed_dim // 4
+    gh = np.arange(grid_h, dtype=np.float32) / spatial_scale
+    gw = np.arange(grid_w, dtype=np.float32) / spatial_scale
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape([2, 1, grid_h, grid_w])
+    emb_a = sincos_1d(d_sp // 2, grid[0])
+    emb_b = sincos_1d(d_sp // 2, grid[1])
+    sp = np.concatenate([emb_a, emb_b], axis=1)                      # [H*W, 3D/4]
+    gt = np.arange(t_size, dtype=np.float32) / temporal_scale
+    tt = sincos_1d(d_t, gt)                                           # [T, D/4]
+    tt = np.repeat(tt[:, None, :], grid_h * grid_w, axis=1)
+    sp = np.repeat(sp[None, :, :], t_size, axis=0)
+    return np.concatenate([tt, sp], axis=-1)
+
+
+def joint_pos_embedding(cfg: DiTConfig, frames: int, height: int, width: int) -> torch.Tensor:
+    """[St + F*h*w, D] fp32; text slots are zero (dit_video_concat.py:188-235)."""
+    p = cfg.patch_size
+    tab = sincos_pos_embed_3d(cfg.inner_dim, height // p, width // p, frames,
+                              cfg.spatial_interpolation_scale, cfg.temporal_interpolation_scale)
+    tab = torch.from_numpy(tab).to(torch.float32).flatten(0, 1)
+    out = torch.zeros(cfg.max_text_seq_length + tab.shape[0], cfg.inner_dim, dtype=torch.float32)
+    out[cfg.max_text_seq_length:] = tab
+    return out
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0,
+                      max_period: float = 10000.0) -> torch.Tensor:
+    """fp32 [B, dim]; cos first when flip_sin_to_cos (cf. videotuna/utils/diffusion_utils.py:9-33)."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    args = t[:, None].to(torch.float32) * torch.exp(exponent)[None]
+    emb = torch.cat([torch.sin(args), torch.cos(args)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def alphas_cumprod_cogvideox(num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                             beta_end: float = 0.012, snr_shift_scale: float = 3.0,
+                             rescale_zero_snr: bool = True) -> torch.Tensor:
+    """fp64 table of abar_t.  scaled-linear betas -> cumprod -> SNR shift -> zero-terminal-SNR
+    (discretizer.py:96-107,123-130; diffusion_utils.py:36-45,141-173)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    ac = ac / (snr_shift_scale + (1.0 - snr_shift_scale) * ac)
+    if rescale_zero_snr:
+        s = ac.sqrt()
+        s0, sT = s[0].clone(), s[-1].clone()
+        s = (s - sT) * (s0 / (s0 - sT))
+        ac = s ** 2
+    return ac
+
+
+# --------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------
+def param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:
+    d, te = cfg.inner_dim, cfg.time_embed_dim
+    p, c = cfg.patch_size, cfg.in_channels
+    hd = cfg.attention_head_dim
+    sh: Dict[str, Tuple[int, ...]] = {
+        "patch_embed.proj.weight": (d, c, p, p), "patch_embed.proj.bias": (d,),
+        "patch_embed.text_proj.weight": (d, cfg.text_embed_dim), "patch_embed.text_proj.bias": (d,),
+        "time_embedding.linear_1.weight": (te, d), "time_embedding.linear_1.bias": (te,),
+        "time_embedding.linear_2.weight": (te, te), "time_embedding.linear_2.bias": (te,),
+        "norm_final.weight": (d,), "norm_final.bias": (d,),
+        "norm_out.linear.weight": (2 * d, te), "norm_out.linear.bias": (2 * d,),
+        "norm_out.norm.weight": (d,), "norm_out.norm.bias": (d,),
+        "proj_out.weight": (p * p * cfg.out_channels, d), "proj_out.bias": (p * p * cfg.out_channels,),
+    }
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sh[b + n + ".linear.weight"] = (6 * d, te)
+            sh[b + n + ".linear.bias"] = (6 * d,)
+            sh[b + n + ".norm.weight"] = (d,)
+            sh[b + n + ".norm.bias"] = (d,)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            sh[b + "attn1." + n + ".weight"] = (d, d)
+            sh[b + "attn1." + n + ".bias"] = (d,)
+        for n in ("norm_q", "norm_k"):
+            sh[b + "attn1." + n + ".weight"] = (hd,)
+            sh[b + "attn1." + n + ".bias"] = (hd,)
+        sh[b + "ff.net.0.proj.weight"] = (cfg.ff_mult * d, d)
+        sh[b + "ff.net.0.proj.bias"] = (cfg.ff_mult * d,)
+        sh[b + "ff.net.2.weight"] = (d, cfg.ff_mult * d)
+        sh[b + "ff.net.2.bias"] = (d,)
+    return sh
+
+
+def init_params(cfg: DiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded random init: W ~ N(0, 0.02^2), LN gamma ~ 1 + N(0,0.02), beta ~ N(0,0.02),
+    biases ~ N(0, 0.02) -- nothing is exactly zero/one so every term carries gradient signal."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, s in param_shapes(cfg).items():
+        w = torch.randn(s, generator=g, dtype=torch.float32) * 0.02
+        if k.endswith("norm.weight") or k.endswith("norm_final.weight") or k.endswith("norm_q.weight") \
+                or k.endswith("norm_k.weight"):
+            w = w + 1.0
+        out[k] = w.to(dtype)
+    return out
+
+
+LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0")
+
+
+def init_lora(cfg: DiTConfig, r: int = 4, seed: int = 1, zero_b: bool = True, dtype=torch.float32
+              ) -> Dict[str, torch.Tensor]:
+    """peft 0.12 default init: A kaiming_uniform(a=sqrt(5)) -> U(-1/sqrt(in), 1/sqrt(in)), B zeros.
+    ``zero_b=False`` draws B ~ N(0, 0.02) so that the adapters change the forward (used in fixtures)."""
+    g = torch.Generator().manual_seed(seed)
+    d = cfg.inner_dim
+    out = {}
+    for i in range(cfg.num_layers):
+        for n in LORA_TARGETS:
+            base = f"transformer_blocks.{i}.attn1.{n}"
+            bound = 1.0 / math.sqrt(d)
+            out[base + ".lora_A.default.weight"] = ((torch.rand((r, d), generator=g) * 2 - 1) * bound).to(dtype)
+            out[base + ".lora_B.default.weight"] = (torch.zeros(d, r) if zero_b
+                                                    else torch.randn((d, r), generator=g) * 0.02).to(dtype)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# the DiT forward (functional; autograd gives the oracle backward)
+# --------------------------------------------------------------------------------------
+def _lin(x, P, name, lora=None, lora_scale=0.25):
+    y = F.linear(x, P[name + ".weight"], P[name + ".bias"])
+    if lora is not None and (name + ".lora_A.default.weight") in lora:
+        A = lora[name + ".lora_A.default.weight"]
+        B = lora[name + ".lora_B.default.weight"]
+        y = y + lora_scale * F.linear(F.linear(x, A), B)
+    return y
+
+
+def gelu_tanh(x):
+    return F.gelu(x, approximate="tanh")
+
+
+def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scale=0.25, taps=None):
+    """One CogVideoXBlock.  h_txt [B,St,D], h_vid [B,Sv,D], emb [B,te]."""
+    d, H, hd = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim
+    St = h_txt.shape[1]
+    B = h_vid.shape[0]
+
+    def ln_zero(name, hv, ht):
+        mod = F.linear(F.silu(emb), P[prefix + name + ".linear.weight"], P[prefix + name + ".linear.bias"])
+        shift, scale, gate, eshift, escale, egate = mod.chunk(6, dim=1)
+        w, b = P[prefix + name + ".norm.weight"], P[prefix + name + ".norm.bias"]
+        nv = F.layer_norm(hv, (d,), w, b, cfg.norm_eps) * (1 + scale)[:, None] + shift[:, None]
+        nt = F.layer_norm(ht, (d,), w, b, cfg.norm_eps) * (1 + escale)[:, None] + eshift[:, None]
+        return nv, nt, gate[:, None], egate[:, None]
+
+    nv, nt, gate, egate = ln_zero("norm1", h_vid, h_txt)
+    x = torch.cat([nt, nv], dim=1)                                   # text first
+    a = prefix + "attn1."
+    q = _lin(x, P, a + "to_q", lora, lora_scale).view(B, -1, H, hd).transpose(1, 2)
+    k = _lin(x, P, a + "to_k", lora, lora_scale).view(B, -1, H, hd).transpose(1, 2)
+    v = _lin(x, P, a + "to_v", lora, lora_scale).view(B, -1, H, hd).transpose(1, 2)
+    q = F.layer_norm(q, (hd,), P[a + "norm_q.weight"], P[a + "norm_q.bias"], cfg.qk_norm_eps)
+    k = F.layer_norm(k, (hd,), P[a + "norm_k.weight"], P[a + "norm_k.bias"], cfg.qk_norm_eps)
+    o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(B, -1, d)
+    if taps is not None:
+        taps[prefix + "attn_core"] = o
+    o = _lin(o, P, a + "to_out.0", lora, lora_scale)
+    h_vid = h_vid + gate * o[:, St:]
+    h_txt = h_txt + egate * o[:, :St]
+
+    nv, nt, gate, egate = ln_zero("norm2", h_vid, h_txt)
+    x = torch.cat([nt, nv], dim=1)
+    f = F.linear(x, P[prefix + "ff.net.0.proj.weight"], P[prefix + "ff.net.0.proj.bias"])
+    f = gelu_tanh(f)
+    f = F.linear(f, P[prefix + "ff.net.2.weight"], P[prefix + "ff.net.2.bias"])
+    h_vid = h_vid + gate * f[:, St:]
+    h_txt = h_txt + egate * f[:, :St]
+    return h_txt, h_vid
+
+
+def dit_forward(P: Dict[str, torch.Tensor], cfg: DiTConfig, hidden_states: torch.Tensor,
+                encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
+                lora: Optional[Dict[str, torch.Tensor]] = None, lora_scale: float = 0.25,
+                taps: Optional[dict] = None) -> torch.Tensor:
+    """hidden_states [B,F,C,H,W], encoder_hidden_states [B,St,text_dim], timestep int64 [B]
+    -> [B,F,C,H,W] (v-prediction)."""
+    dt = hidden_states.dtype
+    B, Fr, C, Hh, Ww = hidden_states.shape
+    p, d = cfg.patch_size, cfg.inner_dim
+    # 1. time embedding: sinusoid(d) -> Linear -> SiLU -> Linear
+    t_emb = timestep_sinusoid(timestep, d, cfg.flip_sin_to_cos, cfg.freq_shift).to(dt)
+    emb = F.linear(t_emb, P["time_embedding.linear_1.weight"], P["time_embedding.linear_1.bias"])
+    emb = F.linear(F.silu(emb), P["time_embedding.linear_2.weight"], P["time_embedding.linear_2.bias"])
+    # 2. patch embed: per-frame Conv2d(k=2,s=2) == Linear over (c p q); text Linear; [text, video]
+    x = hidden_states.reshape(B * Fr, C, Hh, Ww)
+    x = F.conv2d(x, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=p)
+    x = x.view(B, Fr, d, -1).transpose(2, 3).flatten(1, 2)           # [B, F*h*w, d], token order (t h w)
+    txt = F.linear(encoder_hidden_states, P["patch_embed.text_proj.weight"], P["patch_embed.text_proj.bias"])
+    St = txt.shape[1]
+    if not cfg.use_rotary_positional_embeddings:
+        pos = joint_pos_embedding(cfg, Fr, Hh, Ww).to(dt)
+        # text slots of the table are zero; only the first St text tokens are present
+        x = x + pos[cfg.max_text_seq_length:][None]
+    h_txt, h_vid = txt, x
+    if taps is not None:
+        taps["embed_txt"], taps["embed_vid"], taps["emb"] = h_txt, h_vid, emb
+    # 3. blocks
+    for i in range(cfg.num_layers):
+        h_txt, h_vid = dit_block(h_txt, h_vid, emb, P, f"transformer_blocks.{i}.", cfg, lora, lora_scale, taps)
+        if taps is not None:
+            taps[f"block{i}_txt"], taps[f"block{i}_vid"] = h_txt, h_vid
+    # 4. final: LN (video tokens only for 2B) -> AdaLayerNorm(shift, scale) -> proj
+    h = F.layer_norm(h_vid, (d,), P["norm_final.weight"], P["norm_final.bias"], cfg.norm_eps)
+    mod = F.linear(F.silu(emb), P["norm_out.linear.weight"], P["norm_out.linear.bias"])
+    shift, scale = mod.chunk(2, dim=1)
+    h = F.layer_norm(h, (d,), P["norm_out.norm.weight"], P["norm_out.norm.bias"], cfg.norm_eps)
+    h = h * (1 + scale)[:, None] + shift[:, None]
+    h = F.linear(h, P["proj_out.weight"], P["proj_out.bias"])       # [B, Sv, C*p*p] in (c p q) order
+    # 5. unpatchify
+    out = h.reshape(B, Fr, Hh // p, Ww // p, -1, p, p)
+    out = out.permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# training-step math (cogvideo_pl.py:835-886)
+# --------------------------------------------------------------------------------------
+def add_noise(x0, noise, t, abar):
+    a = abar[t].to(x0.dtype)
+    sa = (a ** 0.5).view(-1, *([1] * (x0.dim() - 1)))
+    sb = ((1 - a) ** 0.5).view(-1, *([1] * (x0.dim() - 1)))
+    return sa * x0 + sb * noise
+
+
+def get_velocity(sample, noise, t, abar):
+    """diffusers semantics: sqrt(abar)*noise - sqrt(1-abar)*sample.  The reference calls it as
+    get_velocity(model_output, noisy_model_input, t) (cogvideo_pl.py:872-874) which yields x0-hat for a
+    v-prediction model."""
+    a = abar[t].to(sample.dtype)
+    sa = (a ** 0.5).view(-1, *([1] * (sample.dim() - 1)))
+    sb = ((1 - a) ** 0.5).view(-1, *([1] * (sample.dim() - 1)))
+    return sa * noise - sb * sample
+
+
+def training_loss(P, cfg, x0, text, noise, t, abar, lora=None, lora_scale=0.25, taps=None):
+    """x0 [B,F,C,H,W] latents (already scaled), text [B,St,4096], noise like x0, t int64 [B]."""
+    noisy = add_noise(x0, noise, t, abar)
+    model_out = dit_forward(P, cfg, noisy, text, t, lora, lora_scale, taps)
+    pred = get_velocity(model_out, noisy, t, abar)
+    w = (1.0 / (1.0 - abar[t])).to(x0.dtype).view(-1, 1, 1, 1, 1)
+    B = x0.shape[0]
+    loss = torch.mean((w * (pred - x0) ** 2).reshape(B, -1), dim=1).mean()
+    if taps is not None:
+        taps["model_out"] = model_out
+    return loss
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2):
+    """torch.optim.AdamW semantics (decoupled decay first), in place on fp32 tensors; step is 1-based."""
+    p.mul_(1 - lr * weight_decay)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------------------
+# single-op restatements used by the per-kernel parity tests
+# --------------------------------------------------------------------------------------
+def ln_modulate(x, w, b, scale, shift, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps) * (1 + scale) + shift
+
+
+def attention(q, k, v):
+    """q,k,v [B,H,S,hd] -> o, lse (natural log, scaled scores)."""
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    lse = torch.logsumexp(s, dim=-1)
+    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    return o, lse

@@ -1,0 +1,137 @@
+/* vt355 -- C ABI of the MI355X-native CogVideoX finetune hot path (libvt355.so, gfx950 only).
+ *
+ * The reference (VideoVerses/VideoTuna-dev, pure Python) has NO FFI boundary on this path: the
+ * denoiser is chosen by `target:` reflection (videotuna/utils/common_utils.py:90-109) and every op is
+ * a torch / diffusers / peft call.  This header is the boundary the engine introduces *below* that
+ * Python plug-in point; each entry point names the reference call it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (workspace too);
+ *   - bf16 tensors are raw uint16 storage (`void*`), row-major, innermost stride 1, leading dimensions
+ *     (`ld*`, in elements) given explicitly; 16-byte aligned base pointers unless noted;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no hidden syncs,
+ *     no allocation, no host reads of device data -> safe under hipGraph capture;
+ *   - return 0 on success, a negative VT_ERR_* otherwise; no C++ exception crosses the ABI;
+ *   - reentrant and stateless: safe from autograd's backward thread; one process per GPU.
+ */
+#ifndef VT355_H
+#define VT355_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_OK 0
+#define VT_ERR_BAD_SHAPE (-1)
+#define VT_ERR_BAD_ALIGN (-2)
+#define VT_ERR_LAUNCH (-3)
+#define VT_ERR_UNSUPPORTED (-4)
+
+int vt_version(void);                 /* ABI version, currently 1 */
+const char* vt_arch(void);            /* "gfx950" */
+const char* vt_error_string(int code);
+
+/* GEMM epilogues */
+#define VT_EPI_BIAS 0        /* C = A W^T + bias                                   (nn.Linear)                */
+#define VT_EPI_BIAS_GELU 1   /* C2 = u = A W^T + bias ; C = gelu_tanh(u)           (FeedForward net.0)         */
+#define VT_EPI_GATED_RES 2   /* C = R + gate[b,seg] * (A W^T + bias)               (h += gate * to_out / ff.net.2;
+                                                                                    gate == NULL -> C = R + ...;
+                                                                                    r_mod > 0 -> R row = m % r_mod) */
+#define VT_EPI_DGELU 3       /* C = (A W^T) * gelu_tanh'(U)                        (backward through net.0 act) */
+
+/* C[M,N] = A[M,K] * W[N,K]^T, bf16 operands, fp32 accumulate.  K % 64 == 0, N % 4 == 0.
+ * Replaces: every torch.nn.Linear of diffusers CogVideoXBlock / CogVideoXPatchEmbed / TimestepEmbedding /
+ * CogVideoXLayerNormZero.linear / proj_out, called by the reference via
+ * videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871; rows m belong to sample b = m / S and are text
+ * rows when (m % S) < St (diffusers concatenates [text, video]). */
+int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                 int M, int N, int K, const void* bias, int epilogue, int out_fp32,
+                 const void* R, int ldr, int r_mod,
+                 const float* gate_txt, const float* gate_vid, int gate_bstride, int S, int St,
+                 void* C2, int ldc2, const void* U, int ldu, void* stream);
+
+/* Flash attention forward, head_dim 64, non-causal.  Element (b,s,h,d) of q lives at
+ * q + b*q_bs + s*q_rs + h*64 + d (same for k, v, o) so a fused QKV projection is consumed in place.
+ * lse2[b,h,s] = log2(sum_j exp(scale * q.k_j)) (fp32), kept for the backward.
+ * Replaces: F.scaled_dot_product_attention in diffusers CogVideoXAttnProcessor2_0 (cogvideo_pl.py:865-871). */
+int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float* lse2,
+                     int B, int H, int S,
+                     long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                     long long q_bs, long long k_bs, long long v_bs, long long o_bs,
+                     float softmax_scale, void* stream);
+
+/* Flash attention backward.  delta_ws: [B*H*S] fp32 workspace; dq_f32: fp32 [.., H*64] accumulation buffer
+ * that the CALLER ZEROES beforehand (dQ is summed across key blocks with fp32 atomics); dk, dv bf16.
+ * Replaces: autograd of the SDPA call above (loss.backward() under PL). */
+int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                     const float* lse2, float* delta_ws, float* dq_f32, void* dk, void* dv,
+                     int B, int H, int S,
+                     long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs,
+                     long long dq_rs, long long dk_rs, long long dv_rs,
+                     long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
+                     long long dq_bs, long long dk_bs, long long dv_bs,
+                     float softmax_scale, void* stream);
+
+/* y = LayerNorm(x; gamma, beta, eps) * (1 + scale[b,seg]) + shift[b,seg]; gamma/beta may be NULL (no
+ * affine), the four modulation pointers may be NULL (plain LayerNorm).  mean/rstd [M] fp32 optional.
+ * Replaces: diffusers CogVideoXLayerNormZero.norm + modulate, norm_final, AdaLayerNorm (SURVEY 8(a) a3,a6). */
+int vt_ln_modulate_fwd(const void* x, int ldx, void* y, int ldy, const void* gamma, const void* beta,
+                       const float* shift_txt, const float* scale_txt, const float* shift_vid,
+                       const float* scale_vid, int mod_bstride, float* mean, float* rstd,
+                       int M, int D, int S, int St, float eps, void* stream);
+/* dx = dres + d/dx[ LN-modulate ](dy)  (dres may be NULL) */
+int vt_ln_modulate_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                       const void* gamma, const float* scale_txt, const float* scale_vid, int mod_bstride,
+                       const void* dres, int lddres, void* dx, int lddx,
+                       int M, int D, int S, int St, void* stream);
+
+/* per-head LayerNorm(64, affine) of the q and k thirds of a fused [M, 3*H*64] projection; writes
+ * [M, 2*H*64] (q_hat | k_hat) and the statistics [M, 2H].  Replaces attn.norm_q / attn.norm_k. */
+int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, const void* gq, const void* bq,
+                        const void* gk, const void* bk, float* mean, float* rstd,
+                        long long M, int H, float eps, void* stream);
+int vt_qk_layernorm_bwd(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
+                        const float* mean, const float* rstd, const void* gq, const void* gk,
+                        void* dqkv, int ldd, long long M, int H, void* stream);
+
+/* y[m,:] = x[m,:] * gate[b(m), seg(m)]  (backward of the gated residual) */
+int vt_gate_mul(const void* x, int ldx, void* y, int ldy, const float* g_txt, const float* g_vid, int bstride,
+                long long M, int D, int S, int St, void* stream);
+int vt_silu_bf16(const void* x, void* y, long long n, void* stream);
+int vt_cast_f32_bf16(const float* x, void* y, long long n, void* stream);
+/* sinusoid(t) [B,D] bf16, cos half first when flip_sin_to_cos (diffusers Timesteps; cf. diffusion_utils.py:9-33) */
+int vt_timestep_embedding(const long long* t, void* out, int B, int D, int flip_sin_to_cos, float freq_shift,
+                          void* stream);
+/* [B,F,C,H,W] bf16 <-> tokens [B*F*(H/P)*(W/P), ldt] with columns (c p q) */
+int vt_patchify(const void* img, void* tok, int B, int F, int C, int H, int W, int P, int ldt, void* stream);
+int vt_unpatchify(const void* tok, void* img, int B, int F, int C, int H, int W, int P, int ldt, void* stream);
+
+/* scheduler.add_noise (cogvideo_pl.py:864): noisy = sqrt_ab[b]*x0 + sqrt_1mab[b]*noise  (fp32 in, bf16 out) */
+int vt_add_noise(const float* x0, const float* noise, const float* sqrt_ab, const float* sqrt_1mab, void* noisy,
+                 long long per_sample, int B, void* stream);
+/* cogvideo_pl.py:872-886: x0_hat = sqrt_ab*noisy - sqrt_1mab*v ; loss = mean_b mean_i w_b (x0_hat-x0)^2 ;
+ * optionally d loss / d v * grad_scale (bf16).  partials_ws: >= 512 floats. */
+int vt_diffusion_loss(const void* vpred, const void* noisy, const float* x0, const float* sqrt_ab,
+                      const float* sqrt_1mab, const float* weights, float* loss, float* partials_ws,
+                      void* dvpred, long long per_sample, int B, float grad_scale, void* stream);
+
+/* torch.optim.AdamW step (cogvideo_pl.py:774-779) over one flat fp32 buffer; g is multiplied by grad_scale
+ * first; p_bf16 (optional) receives the bf16 compute copy. step is 1-based. */
+int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* LoRA (peft LoraLayer, cogvideo_pl.py:143-149) */
+int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,
+                 void* stream);                                  /* T[M,16] = X A^T                     */
+int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
+                 long long osr, float alpha, long long M, int P, void* stream);
+                                                                 /* out[p*osp+r*osr] += alpha*sum_m Big[m,p]*Small[m,r] */
+int vt_lora_up_add(void* dX, int ldx, const void* dT, int ldt, const void* A, int lda, int R, long long M, int K,
+                   void* stream);                                /* dX += dT A                          */
+int vt_lora_pack_b(const float* Bcat, void* Wext, int ldw, int n_adapters, int d_out, int r, float scale, void* stream);
+int vt_lora_pack_bt(const float* Bcat, void* WText, int ldwt, int n_adapters, int d_out, int r, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

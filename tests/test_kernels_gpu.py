@@ -1,0 +1,276 @@
+"""Per-kernel parity: every HIP entry point (called through the C-ABI) against the CPU oracle / a plain
+fp32 PyTorch restatement of the same op on the same seeded inputs.  Tolerances are bf16-storage
+tolerances (8 significant bits): outputs are compared with rtol/atol ~1-2e-2 against an fp32 reference fed
+with the SAME bf16-rounded inputs; fp32 outputs (LSE, statistics, loss, AdamW) use 1e-4..1e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cogvideox_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(x):      # bf16-round but keep fp32 (what the device kernel actually sees)
+    return x.to(BF).float()
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().float().cpu(); b = b.detach().float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).float().mean().item()
+    assert bad == 0.0, f"{what}: {bad*100:.4f}% out of tol, max err {err.max().item():.4g}, ref absmax {b.abs().max().item():.4g}"
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 1984, 1920), (129, 128, 64), (2, 1536, 512), (17776, 1920, 1984)])
+def test_gemm_bias(dev, M, N, K):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) * 0.05); b = rb(torch.randn(N, generator=g))
+    ref = a @ w.T + b
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.gemm(a.to(dev, BF), w.to(dev, BF), out, b.to(dev, BF))
+    close(out, ref, 1e-2, 1e-2, "gemm bf16 out")
+    out32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev, BF), w.to(dev, BF), out32, b.to(dev, BF))
+    close(out32, ref, 1e-4, 2e-3, "gemm fp32 out")
+
+
+def test_gemm_strided_and_epilogues(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(7)
+    B, S, St, K, N = 2, 150, 20, 128, 256
+    M = B * S
+    abig = rb(torch.randn(M, K + 64, generator=g))            # lda > K (extension columns ignored via K=)
+    w = rb(torch.randn(N, K, generator=g) * 0.1); bias = rb(torch.randn(N, generator=g))
+    a = abig[:, :K]
+    A = abig.to(dev, BF); W = w.to(dev, BF); Bi = bias.to(dev, BF)
+    # GELU epilogue: two outputs
+    u_ref = a @ w.T + bias
+    out = torch.empty(M, N, dtype=BF, device=dev); pre = torch.empty(M, N, dtype=BF, device=dev)
+    ops.gemm(A, W, out, Bi, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre, K=K)
+    close(pre, u_ref, 1e-2, 1e-2, "pre-activation")
+    close(out, F.gelu(u_ref, approximate="tanh"), 1e-2, 1e-2, "gelu")
+    # gated residual, text/video gates per sample
+    R = rb(torch.randn(M, N, generator=g)); gates = torch.randn(B, 2, N, generator=g)
+    gate_rows = torch.stack([gates[m // S, 0 if (m % S) < St else 1] for m in range(M)])
+    ref = R + gate_rows * u_ref
+    G = gates.to(dev)
+    ops.gemm(A, W, out, Bi, epilogue=ops.EPI_GATED_RES, residual=R.to(dev, BF), gate_txt=G[:, 0], gate_vid=G[:, 1],
+             gate_bstride=2 * N, S=S, St=St, K=K)
+    close(out, ref, 1e-2, 2e-2, "gated residual")
+    # positional-table add (gate None, r_mod)
+    tab = rb(torch.randn(S, N, generator=g))
+    ops.gemm(A, W, out, Bi, epilogue=ops.EPI_GATED_RES, residual=tab.to(dev, BF), r_mod=S, K=K)
+    close(out, tab.repeat(B, 1) + u_ref, 1e-2, 2e-2, "pos add")
+    # dGELU
+    U = rb(torch.randn(M, N, generator=g))
+    uu = U.clone().requires_grad_(True)
+    F.gelu(uu, approximate="tanh").sum().backward()
+    ops.gemm(A, W, out, None, epilogue=ops.EPI_DGELU, pre_act_in=U.to(dev, BF), K=K)
+    close(out, (a @ w.T) * uu.grad, 1e-2, 2e-2, "dgelu")
+
+
+# ------------------------------------------------------------------ attention
+def _qkv(B, S, H, g, spike=False):
+    qkv = torch.randn(B, S, 3, H, 64, generator=g)
+    if spike:
+        qkv[:, S // 2, 1] *= 6.0        # one key row much larger: forces the running max to jump mid-stream
+        qkv[:, 3, 0] *= 4.0
+    return rb(qkv)
+
+
+@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 1250, 2, False)])
+def test_attn_fwd(dev, B, S, H, spike):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(S)
+    qkv = _qkv(B, S, H, g, spike)
+    q, k, v = [qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3)]
+    o_ref, lse_ref = O.attention(q, k, v)
+    d = qkv.to(dev, BF).view(B, S, 3 * H * 64)
+    o = torch.empty(B, S, H * 64, dtype=BF, device=dev)
+    lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(d[:, :, :H * 64], d[:, :, H * 64:2 * H * 64], d[:, :, 2 * H * 64:], o, lse2, B, H, S)
+    close(o.view(B, S, H, 64).permute(0, 2, 1, 3), o_ref, 2e-2, 1e-2, "attn out")
+    close(lse2 * math.log(2.0), lse_ref, 1e-4, 2e-3, "lse")
+
+
+@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 700, 2, False)])
+def test_attn_bwd(dev, B, S, H, spike):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(S + 1)
+    qkv = _qkv(B, S, H, g, spike)
+    do = rb(torch.randn(B, S, H, 64, generator=g))
+    qkv64 = qkv.double().requires_grad_(True)
+    q, k, v = [qkv64[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    o_ref, _ = O.attention(q, k, v)
+    o_ref.backward(do.permute(0, 2, 1, 3).double())
+    dref = qkv64.grad                                   # [B,S,3,H,64]
+    d = qkv.to(dev, BF).view(B, S, 3 * H * 64)
+    D = H * 64
+    qd, kd, vd = d[:, :, :D], d[:, :, D:2 * D], d[:, :, 2 * D:]
+    o = torch.empty(B, S, D, dtype=BF, device=dev); lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(qd, kd, vd, o, lse2, B, H, S)
+    dq = torch.zeros(B, S, D, dtype=torch.float32, device=dev)
+    dk = torch.empty(B, S, D, dtype=BF, device=dev); dv = torch.empty(B, S, D, dtype=BF, device=dev)
+    delta = torch.empty(B * H * S, dtype=torch.float32, device=dev)
+    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(B, S, D), lse2, delta, dq, dk, dv, B, H, S)
+    scale = dref.abs().max().item()
+    close(dq.view(B, S, H, 64), dref[:, :, 0], 3e-2, 1e-2 * scale, "dq")
+    close(dk.view(B, S, H, 64), dref[:, :, 1], 3e-2, 1e-2 * scale, "dk")
+    close(dv.view(B, S, H, 64), dref[:, :, 2], 3e-2, 1e-2 * scale, "dv")
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("D", [128, 1920, 3072])
+def test_ln_modulate(dev, D):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(D)
+    B, S, St = 2, 37, 5
+    M = B * S
+    x = rb(torch.randn(M, D, generator=g) * 2 + 0.5)
+    ga = rb(1 + 0.1 * torch.randn(D, generator=g)); be = rb(0.1 * torch.randn(D, generator=g))
+    mod = torch.randn(B, 6 * D, generator=g) * 0.3          # shift, scale, gate, eshift, escale, egate
+    rows_b = torch.arange(M) // S
+    is_txt = (torch.arange(M) % S) < St
+    shift = torch.where(is_txt[:, None], mod[rows_b, 3 * D:4 * D], mod[rows_b, 0:D])
+    scale = torch.where(is_txt[:, None], mod[rows_b, 4 * D:5 * D], mod[rows_b, D:2 * D])
+    xx = x.clone().requires_grad_(True)
+    ref = O.ln_modulate(xx, ga, be, scale, shift, 1e-5)
+    dy = rb(torch.randn(M, D, generator=g)); dres = rb(torch.randn(M, D, generator=g))
+    ref.backward(dy)
+    X = torch.zeros(M, D + 64, dtype=BF, device=dev); X[:, :D] = x.to(dev, BF)      # strided input
+    Y = torch.empty(M, D + 64, dtype=BF, device=dev)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    Md = mod.to(dev)
+    ops.ln_modulate_fwd(X, Y, ga.to(dev, BF), be.to(dev, BF),
+                        (Md[:, 3 * D:], Md[:, 4 * D:], Md[:, 0:], Md[:, D:], 6 * D), mean, rstd, D, S, St, 1e-5)
+    close(Y[:, :D], ref, 1e-2, 2e-2, "ln_modulate fwd")
+    close(mean, x.mean(1), 1e-4, 1e-4, "mean")
+    dx = torch.empty(M, D, dtype=BF, device=dev)
+    ops.ln_modulate_bwd(dy.to(dev, BF), X, mean, rstd, ga.to(dev, BF), (Md[:, 4 * D:], Md[:, D:], 6 * D),
+                        dres.to(dev, BF), dx, D, S, St)
+    close(dx, xx.grad + dres, 2e-2, 2e-2, "ln_modulate bwd")
+    # plain LayerNorm (no modulation, affine) == norm_final
+    ops.ln_modulate_fwd(X, Y, ga.to(dev, BF), be.to(dev, BF), None, None, None, D, S, St, 1e-5)
+    close(Y[:, :D], F.layer_norm(x, (D,), ga, be, 1e-5), 1e-2, 2e-2, "plain LN")
+
+
+def test_qk_layernorm(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(11)
+    M, H = 203, 3
+    D = H * 64
+    qkv = rb(torch.randn(M, 3 * D, generator=g) * 1.5)
+    gq, bq, gk, bk = [rb(t) for t in (1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g),
+                                       1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g))]
+    x = qkv.clone().requires_grad_(True)
+    qh = F.layer_norm(x[:, :D].view(M, H, 64), (64,), gq, bq, 1e-6).reshape(M, D)
+    kh = F.layer_norm(x[:, D:2 * D].view(M, H, 64), (64,), gk, bk, 1e-6).reshape(M, D)
+    dqh = torch.randn(M, D, generator=g); dkh = rb(torch.randn(M, D, generator=g))
+    (qh * dqh).sum().add((kh * dkh).sum()).backward()
+    Q = qkv.to(dev, BF); out = torch.empty(M, 2 * D, dtype=BF, device=dev)
+    mean = torch.empty(M, 2 * H, device=dev); rstd = torch.empty(M, 2 * H, device=dev)
+    dv = [t.to(dev, BF) for t in (gq, bq, gk, bk)]
+    ops.qk_layernorm_fwd(Q, out, dv[0], dv[1], dv[2], dv[3], mean, rstd, H, 1e-6)
+    close(out[:, :D], qh, 1e-2, 2e-2, "q_hat"); close(out[:, D:], kh, 1e-2, 2e-2, "k_hat")
+    dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
+    ops.qk_layernorm_bwd(dqh.to(dev), dkh.to(dev, BF), Q, mean, rstd, dv[0], dv[2], dqkv, H)
+    close(dqkv[:, :2 * D], x.grad[:, :2 * D], 2e-2, 2e-2, "qk-LN bwd")
+
+
+# ------------------------------------------------------------------ elementwise
+def test_timestep_embedding_golden(dev):
+    from vt355 import ops
+    gold = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "timestep_embedding.npz"))
+    t = torch.from_numpy(gold["t"]).to(dev)
+    out = torch.empty(len(t), 1920, dtype=BF, device=dev)
+    ops.timestep_embedding(t, out)
+    close(out, torch.from_numpy(gold["emb1920"]), 8e-3, 8e-3, "sinusoid vs reference golden")
+
+
+def test_patchify_roundtrip_and_order(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(3)
+    B, Fr, C, H, W, P = 2, 3, 16, 6, 8, 2
+    img = rb(torch.randn(B, Fr, C, H, W, generator=g))
+    tok = torch.empty(B * Fr * (H // P) * (W // P), C * P * P, dtype=BF, device=dev)
+    ops.patchify(img.to(dev, BF), tok, P)
+    # oracle order: conv2d weight flattened (c p q); tokens (t h w)
+    ref = img.reshape(B, Fr, C, H // P, P, W // P, P).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, C * P * P)
+    close(tok, ref, 0, 0, "patchify")
+    back = torch.empty(B, Fr, C, H, W, dtype=BF, device=dev)
+    ops.unpatchify(tok, back, P)
+    close(back, img, 0, 0, "unpatchify roundtrip")
+
+
+def test_noise_loss_adamw(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(5)
+    B, per = 3, 4 * 16 * 6 * 8
+    abar = O.alphas_cumprod_cogvideox()
+    t = torch.tensor([10, 500, 990])
+    x0 = torch.randn(B, per, generator=g); nz = torch.randn(B, per, generator=g)
+    sa = abar[t].sqrt().float(); sb = (1 - abar[t]).sqrt().float(); w = (1 / (1 - abar[t])).float()
+    noisy = torch.empty(B, per, dtype=BF, device=dev)
+    ops.add_noise(x0.to(dev), nz.to(dev), sa.to(dev), sb.to(dev), noisy)
+    close(noisy, O.add_noise(x0, nz, t, abar.float()), 1e-2, 1e-2, "add_noise")
+    v = rb(torch.randn(B, per, generator=g)).requires_grad_(True)
+    nb = noisy.float().cpu()
+    pred = O.get_velocity(v, nb, t, abar.float())
+    loss_ref = torch.mean((w[:, None] * (pred - x0) ** 2), dim=1).mean()
+    loss_ref.backward()
+    loss = torch.zeros(1, device=dev); part = torch.empty(512, device=dev); dvp = torch.empty(B, per, dtype=BF, device=dev)
+    ops.diffusion_loss(v.detach().to(dev, BF), noisy, x0.to(dev), sa.to(dev), sb.to(dev), w.to(dev), loss, part, dvp, 1.0)
+    close(loss, loss_ref.reshape(1), 1e-4, 1e-5, "loss")
+    close(dvp, v.grad, 1e-2, 1e-2 * v.grad.abs().max().item(), "dloss/dv")
+    # AdamW vs torch.optim.AdamW over 3 steps
+    n = 5000
+    p = torch.randn(n, generator=g); gr = [torch.randn(n, generator=g) * 0.1 for _ in range(3)]
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-2)
+    P = p.to(dev); Mo = torch.zeros(n, device=dev); Vo = torch.zeros(n, device=dev); Pb = torch.empty(n, dtype=BF, device=dev)
+    for i in range(3):
+        pt.grad = gr[i].clone(); opt.step()
+        ops.adamw(P, gr[i].to(dev), Mo, Vo, Pb, 1e-2, 0.9, 0.999, 1e-8, 1e-2, i + 1)
+    close(P, pt, 1e-5, 1e-6, "adamw")
+    close(Pb, pt, 1e-2, 1e-3, "adamw bf16 copy")
+
+
+# ------------------------------------------------------------------ LoRA
+def test_lora_kernels(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(9)
+    M, K, N, r = 333, 128, 256, 4
+    x = rb(torch.randn(M, K, generator=g)); A = rb(torch.randn(12, K, generator=g) * 0.1)
+    X = torch.zeros(M, K + 64, dtype=BF, device=dev); X[:, :K] = x.to(dev, BF)
+    ops.lora_down(X, A.to(dev, BF), 12, X[:, K:], K)
+    close(X[:, K:K + 12], x @ A.T, 1e-2, 1e-2, "lora_down")
+    assert X[:, K + 12:].abs().max().item() == 0.0
+    dy = rb(torch.randn(M, N, generator=g)); T = X[:, K:K + 16].float().cpu()
+    out = torch.zeros(N, r, device=dev)
+    ops.skinny_tn(dy.to(dev, BF), X[:, K + 4:], r, out, r, 1, 0.25, N)
+    close(out, 0.25 * dy.T @ T[:, 4:8], 1e-3, 1e-2, "skinny_tn R=4")
+    out16 = torch.zeros(12, K, device=dev)
+    dT = rb(torch.randn(M, 16, generator=g)); dT[:, 12:] = 0
+    ops.skinny_tn(X, dT.to(dev, BF), 12, out16, 1, K, 1.0, K)
+    close(out16, dT[:, :12].T @ x, 1e-3, 1e-2, "skinny_tn R=12")
+    dx = rb(torch.randn(M, K, generator=g)); DX = dx.to(dev, BF).clone()
+    ops.lora_up_add(DX, dT.to(dev, BF), A.to(dev, BF), 12, K)
+    close(DX, dx + dT[:, :12] @ A, 1e-2, 2e-2, "lora_up_add")
+    Bc = torch.randn(3 * N, r, generator=g)
+    W = torch.full((3 * N, K + 64), 7.0, dtype=BF, device=dev)
+    ops.lora_pack_b(Bc.to(dev), W[:, K:], K + 64, 3, N, r, 0.25)
+    ref = torch.zeros(3 * N, 64)
+    for j in range(3):
+        ref[j * N:(j + 1) * N, j * r:(j + 1) * r] = 0.25 * Bc[j * N:(j + 1) * N]
+    close(W[:, K:], ref, 1e-2, 1e-3, "pack_b"); assert (W[:, :K] == 7).all()
+    WT = torch.full((K + 64, 3 * N), 7.0, dtype=BF, device=dev)
+    ops.lora_pack_bt(Bc.to(dev), WT[K:], 3 * N, 3, N, r, 0.25)
+    close(WT[K:], ref.T, 1e-2, 1e-3, "pack_bt")

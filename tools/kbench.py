@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at the CogVideoX-2B shapes (random data, HIP events on the launch stream)."""
+import sys, os, json, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vt355 import ops
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    which = sys.argv[1:] or ["gemm", "attn", "mem"]
+    S, H, d = 17776, 30, 1920
+    res = {}
+    if "gemm" in which:
+        for (M, N, K, name) in [(S, 5760, 1984, "qkv"), (S, 1920, 1984, "out"), (S, 7680, 1920, "ff1"), (S, 1920, 7680, "ff2"),
+                                (S, 1984, 5760, "dqkv"), (4096, 4096, 4096, "sq4k"), (8192, 8192, 8192, "sq8k")]:
+            a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
+            out = torch.empty(M, N, dtype=BF, device=dev); b = torch.zeros(N, dtype=BF, device=dev)
+            med, mn = timeit(lambda: ops.gemm(a, w, out, b))
+            tf = 2.0 * M * N * K / med / 1e9
+            res["gemm_" + name] = dict(ms=med, tflops=tf)
+            print(f"gemm {name:5s} M={M} N={N} K={K}: {med:.3f} ms  {tf:.0f} TF/s (min {mn:.3f})", flush=True)
+            if name == "ff1":
+                pre = torch.empty(M, N, dtype=BF, device=dev)
+                med, mn = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))
+                print(f"   +gelu epilogue: {med:.3f} ms {2.0*M*N*K/med/1e9:.0f} TF/s", flush=True)
+    if "attn" in which:
+        B = 1
+        qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)
+        q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        o = torch.empty(B, S, d, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+        med, mn = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, B, H, S), iters=5, warm=2)
+        fl = 4.0 * S * S * d * B
+        res["attn_fwd"] = dict(ms=med, tflops=fl / med / 1e9)
+        print(f"attn fwd: {med:.3f} ms  {fl/med/1e9:.0f} TF/s (min {mn:.3f})", flush=True)
+        do = torch.randn(B, S, d, device=dev).to(BF)
+        dq = torch.zeros(B, S, d, device=dev); dk = torch.empty(B, S, d, dtype=BF, device=dev); dv = torch.empty_like(dk)
+        delta = torch.empty(B * H * S, device=dev)
+        med, mn = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S), iters=5, warm=2)
+        fl2 = 2.5 * fl
+        res["attn_bwd"] = dict(ms=med, tflops_exec=fl2 / med / 1e9, tflops_alg=2 * fl / med / 1e9)
+        print(f"attn bwd: {med:.3f} ms  {fl2/med/1e9:.0f} TF/s executed (5 products), {2*fl/med/1e9:.0f} algorithmic (min {mn:.3f})", flush=True)
+    if "mem" in which:
+        M = S
+        x = torch.randn(M, d + 64, device=dev).to(BF); y = torch.empty_like(x)
+        ga = torch.ones(d, dtype=BF, device=dev); be = torch.zeros(d, dtype=BF, device=dev)
+        mod = torch.randn(1, 6 * d, device=dev); mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+        m4 = (mod[:, 3 * d:], mod[:, 4 * d:], mod[:, 0:], mod[:, d:], 6 * d)
+        med, _ = timeit(lambda: ops.ln_modulate_fwd(x, y, ga, be, m4, mean, rstd, d, S, 226, 1e-5))
+        print(f"ln_modulate fwd: {med*1e3:.1f} us  {2*M*d*2/med/1e6:.0f} GB/s", flush=True)
+        dx = torch.empty(M, d, dtype=BF, device=dev)
+        med, _ = timeit(lambda: ops.ln_modulate_bwd(y, x, mean, rstd, ga, (mod[:, 4 * d:], mod[:, d:], 6 * d), dx, dx, d, S, 226))
+        print(f"ln_modulate bwd: {med*1e3:.1f} us  {4*M*d*2/med/1e6:.0f} GB/s", flush=True)
+        qkv = torch.randn(M, 3 * d, device=dev).to(BF); out = torch.empty(M, 2 * d, dtype=BF, device=dev)
+        g64 = torch.ones(64, dtype=BF, device=dev); b64 = torch.zeros(64, dtype=BF, device=dev)
+        mq = torch.empty(M, 2 * H, device=dev); rq = torch.empty(M, 2 * H, device=dev)
+        med, _ = timeit(lambda: ops.qk_layernorm_fwd(qkv, out, g64, b64, g64, b64, mq, rq, H, 1e-6))
+        print(f"qk_layernorm fwd: {med*1e3:.1f} us  {4*M*d*2/med/1e6:.0f} GB/s", flush=True)
+        A = torch.randn(16, d, device=dev).to(BF)
+        med, _ = timeit(lambda: ops.lora_down(x, A, 12, x[:, d:], d))
+        print(f"lora_down: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        out16 = torch.zeros(16, d, device=dev)
+        med, _ = timeit(lambda: ops.skinny_tn(x, x[:, d:], 12, out16, 1, d, 1.0, d))
+        print(f"skinny_tn R=12 P=1920: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        ob = torch.zeros(d, 4, device=dev)
+        med, _ = timeit(lambda: ops.skinny_tn(qkv, x[:, d:], 4, ob, 4, 1, 0.25, d))
+        print(f"skinny_tn R=4 P=1920 (ld 5760): {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        med, _ = timeit(lambda: ops.lora_up_add(dx, x[:, d:], A, 12, d))
+        print(f"lora_up_add: {med*1e3:.1f} us  {2*M*d*2/med/1e6:.0f} GB/s", flush=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""ctypes loader for libvt355.so (the C-ABI declared in include/vt355.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class VtError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libvt355.so")
+
+
+# name -> argtypes ; all return int unless listed in _RESTYPE
+_vp, _i, _ll, _f, _fp = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p
+PROTOTYPES = {
+    "vt_version": [],
+    "vt_arch": [],
+    "vt_error_string": [_i],
+    "vt_gemm_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _fp, _fp, _i, _i, _i,
+                     _vp, _i, _vp, _i, _vp],
+    "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+    "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
+                         _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+    "vt_ln_modulate_fwd": [_vp, _i, _vp, _i, _vp, _vp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp],
+    "vt_ln_modulate_bwd": [_vp, _i, _vp, _i, _fp, _fp, _vp, _fp, _fp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _vp],
+    "vt_qk_layernorm_bwd": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _vp, _vp, _vp, _i, _ll, _i, _vp],
+    "vt_gate_mul": [_vp, _i, _vp, _i, _fp, _fp, _i, _ll, _i, _i, _i, _vp],
+    "vt_silu_bf16": [_vp, _vp, _ll, _vp],
+    "vt_cast_f32_bf16": [_fp, _vp, _ll, _vp],
+    "vt_timestep_embedding": [_vp, _vp, _i, _i, _i, _f, _vp],
+    "vt_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "vt_unpatchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "vt_add_noise": [_fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
+    "vt_diffusion_loss": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _f, _vp],
+    "vt_adamw": [_fp, _fp, _fp, _fp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp],
+    "vt_lora_down": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _vp],
+    "vt_skinny_tn": [_vp, _i, _vp, _i, _i, _fp, _ll, _ll, _f, _ll, _i, _vp],
+    "vt_lora_up_add": [_vp, _i, _vp, _i, _vp, _i, _i, _ll, _i, _vp],
+    "vt_lora_pack_b": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
+    "vt_lora_pack_bt": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
+}
+_RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p}
+
+
+def load_library():
+    """Load libvt355.so once; raise VtError (never fall back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise VtError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(videotuna-dev_amd/csrc/build.sh). There is no CPU / eager fallback.")
+    lib = C.CDLL(path)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here means header and library disagree
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _LIB = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        lib = load_library()
+        raise VtError(f"{what} failed: {lib.vt_error_string(code).decode()} (code {code})")

@@ -1,0 +1,231 @@
+// Flash-attention forward, head_dim 64, bf16 in / fp32 accumulate, non-causal, no mask, for gfx950.
+//
+// Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0, reached by the
+// reference at videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871: joint text+video
+// self-attention, q,k,v [B,30,17776,64] at the benchmark shape.
+//
+// Structure: one workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+// K/V tiles of 64 keys are staged global -> VGPR -> LDS (double buffered, loads of tile t+1 in flight
+// while tile t is consumed).  Scores are computed TRANSPOSED, S^T = K * Q^T with
+// v_mfma_f32_32x32x16_bf16, so a lane owns one query column and 2x16 keys: the online-softmax row
+// reductions are lane-local plus one cross-half exchange, and the fp32 P^T accumulator tile is, after
+// bf16 packing, directly the B operand of the second product O^T += V^T * P^T (no LDS round trip for
+// P).  V^T fragments come from the row-major V tile through ds_read_b64_tr_b16.
+// Layout contract: q/k/v/o are addressed as ptr + b*batch_stride + s*row_stride + h*64 + d, so the
+// fused QKV GEMM output [B*S, 3*H*64] is consumed in place (no head transpose copies).
+#include "common.h"
+
+struct AttnFwdParams {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;
+    float* lse2;     // [B,H,S] fp32: log2-domain logsumexp of (score * scale_log2)
+    int S, H, B;
+    long long q_rs, k_rs, v_rs, o_rs;
+    long long q_bs, k_bs, v_bs, o_bs;
+    float scale_log2;
+};
+
+#define FQ 128      // queries per workgroup
+#define FK 64       // keys per tile
+#define NEG_BIG (-1.0e30f)
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];   // 2 x (K 8 KiB + V 8 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nqt = (p.S + FQ - 1) / FQ;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt;
+    const int bh = id / nqt;
+    const int head = bh % p.H, b = bh / p.H;
+    const int q0 = qt * FQ + wave * 32;
+
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 64;
+    const bf16_t* kb = p.k + (size_t)b * p.k_bs + head * 64;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 64;
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 128));
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+r][16s + 8h .. +7] ----
+    bf16x8 qf[4];
+    {
+        int qrow = q0 + r;
+        if (qrow > p.S - 1) qrow = p.S - 1;       // clamp: rows past the end are computed but never stored
+        const bf16_t* qp = qb + (size_t)qrow * p.q_rs + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    }
+
+    // ---- staging assignment: 2 x 16-byte chunks of K and of V per thread per tile ----
+    int k_voff[2], v_voff[2], k_lds[2], v_lds[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int i = tid + 256 * j;
+        int key = i >> 3, c = i & 7;
+        k_voff[j] = (int)(key * p.k_rs * 2) + c * 16;
+        v_voff[j] = (int)(key * p.v_rs * 2) + c * 16;
+        k_lds[j] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
+        v_lds[j] = 8192 + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4);
+    }
+    u32x4 gk[2], gv[2];
+    auto gload = [&](int t) {
+        const int ks = (int)((long long)t * FK * p.k_rs * 2);
+        const int vs = (int)((long long)t * FK * p.v_rs * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gk[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, k_voff[j], ks, 0));
+            gv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[j], vs, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * 16384;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *(u32x4*)(base + k_lds[j]) = gk[j];
+            *(u32x4*)(base + v_lds[j]) = gv[j];
+        }
+    };
+
+    // ---- per-lane LDS read offsets ----
+    int kfo[4];                                   // K fragment, k-step s: row r, chunk (2s+h) swizzled
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kfo[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) << 4);
+    int vfo[2];                                   // V^T fragment (transposed read), d-tile dt
+    {
+        const int g = lane >> 4;                  // 16-lane group
+        const int ql = (lane & 15) >> 2;          // block row supplied by this lane
+        const int pl = lane & 3;                  // 4-column piece supplied by this lane
+        const int keyl = 4 * (g >> 1) + ql;       // + 32*kt2 + 16*s' (+8)
+        const int x = (ql >> 1) & 1;              // ((key >> 1) & 1) for every key this lane addresses
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            int chunk = 4 * dt + 2 * (g & 1) + (pl >> 1);
+            vfo[dt] = 8192 + keyl * 128 + ((chunk ^ (x << 2)) << 4) + (pl & 1) * 8;
+        }
+    }
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
+    float m_run = NEG_BIG, l_run = 0.f;
+    const float sc = p.scale_log2;
+
+    const int nt = (p.S + FK - 1) / FK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* base = smem + buf * 16384;
+
+        // ---- S^T = K Q^T : 2 key sub-tiles x 4 k-steps ----
+        f32x16 st[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2) {
+                bf16x8 kf = *(const bf16x8*)(base + kt2 * 4096 + kfo[s]);
+                st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt2], 0, 0, 0);
+            }
+        }
+        // ---- mask the ragged last tile ----
+        if ((t + 1) * FK > p.S) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int key = t * FK + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= p.S) st[kt2][i] = NEG_BIG;
+                }
+        }
+        // ---- online softmax (log2 domain) ----
+        float mx = st[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float pv = __builtin_amdgcn_exp2f(st[kt2][i] * sc - m_new);
+                st[kt2][i] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+
+        // ---- O^T += V^T P^T : 2 d-tiles x (2 key sub-tiles x 2 k-steps) ----
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kt2][8 * s2 + j];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vp = base + vfo[dt] + (kt2 * 32 + s2 * 16) * 128;
+                    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp));
+                    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp + 8 * 128));
+                    typedef __attribute__((ext_vector_type(8))) short short8v;
+                    short8v v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, o_acc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finalize: O = O^T / l, LSE ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + r;
+    if (qrow < p.S) {
+        bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = pack2(o_acc[dt][4 * g4 + 0] * inv, o_acc[dt][4 * g4 + 1] * inv);
+                w[1] = pack2(o_acc[dt][4 * g4 + 2] * inv, o_acc[dt][4 * g4 + 3] * inv);
+                *(u32x2*)(op + dt * 32 + 8 * g4 + 4 * h) = w;
+            }
+        if (h == 0) p.lse2[((size_t)b * p.H + head) * p.S + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
+    }
+}
+
+extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float* lse2,
+                                int B, int H, int S,
+                                long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                                long long q_bs, long long k_bs, long long v_bs, long long o_bs,
+                                float softmax_scale, void* stream) {
+    if (B <= 0 || H <= 0 || S <= 0) return VT_ERR_BAD_SHAPE;
+    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4))
+        return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return VT_ERR_BAD_ALIGN;
+    if (((uintptr_t)o) & 7) return VT_ERR_BAD_ALIGN;
+    if ((long long)S * k_rs * 2 >= 0x7fffffffLL || (long long)S * v_rs * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    AttnFwdParams p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse2 = lse2;
+    p.S = S; p.H = H; p.B = B;
+    p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const int nqt = (S + FQ - 1) / FQ;
+    hipLaunchKernelGGL(attn_fwd_hd64_kernel, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -1,0 +1,245 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue), fp32 accumulate.
+//
+// Both operands are K-contiguous ("TN"), which is what every linear layer of the DiT needs in the
+// forward (W = nn.Linear weight [out,in]) and, with a pre-transposed copy of the weight, in the
+// backward dX = dY * W.  Reference ops replaced: every nn.Linear of diffusers' CogVideoXBlock that
+// the reference reaches through videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871 (SURVEY 8(a) a4,a5).
+//
+// Structure (v1): 128x128x64 workgroup tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16.  Operands are staged global -> VGPR -> LDS (XOR-swizzled 16-byte chunks,
+// conflict-free ds_read_b128), double-buffered so the loads of K-tile t+1 are in flight while tile t
+// is multiplied (issue-early / write-late).  Global loads are bounds-checked raw buffer loads, so
+// ragged M / N edges read zeros.  The MFMA is issued as (W-frag, A-frag) so each lane ends up with 4
+// consecutive output columns of one row; the accumulators go through LDS once so the epilogue reads
+// residual / writes C in row-contiguous, fully coalesced 128-B segments.
+#include "common.h"
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* C;
+    const bf16_t* bias;       // [N] or null
+    const bf16_t* R;          // residual [*, ldr] (EPI_GATED_RES)
+    const float* gate_txt;    // fp32 gate for rows with (m % S) <  St, indexed [b*gate_bstride + n]
+    const float* gate_vid;    // fp32 gate for rows with (m % S) >= St
+    bf16_t* C2;               // second output: pre-activation (EPI_BIAS_GELU)
+    const bf16_t* U;          // saved pre-activation (EPI_DGELU)
+    int M, N, K;
+    int lda, ldw, ldc, ldr, ldc2, ldu;
+    int S, St, gate_bstride;  // rows per sample, text rows per sample, gate batch stride (elements)
+    int r_mod;                // if > 0 the residual row is (m % r_mod)  (positional table add)
+};
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_DGELU = 3 };
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define CS_LD 132   // fp32 row stride of the epilogue staging tile (64 rows x 132 floats = 33 KiB)
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    // XCD-aware id, then grouped ordering (8 row-tiles per group, column-tiles outer)
+    const int id = xcd_remap(blockIdx.x, nbm * nbn);
+    const int GM = 8;
+    const int in_group = GM * nbn;
+    const int group = id / in_group;
+    const int first_m = group * GM;
+    const int gsz = min(nbm - first_m, GM);
+    const int tile_m = first_m + (id % in_group) % gsz;
+    const int tile_n = (id % in_group) / gsz;
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
+
+    // bounds-checked descriptors rooted at this tile's first row
+    const long long a_rem = (long long)(p.M - row0) * p.lda * 2;
+    const long long w_rem = (long long)(p.N - col0) * p.ldw * 2;
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (size_t)row0 * p.lda, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(p.W + (size_t)col0 * p.ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
+
+    // staging assignment: 4 x 16-byte chunks of A and of W per thread per K-tile
+    int a_voff[4], w_voff[4], lds_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int i = tid + 256 * j;
+        int r = i >> 3, c = i & 7;
+        a_voff[j] = r * p.lda * 2 + c * 16;
+        w_voff[j] = r * p.ldw * 2 + c * 16;
+        lds_off[j] = r * 128 + ((c ^ (r & 7)) << 4);
+    }
+    u32x4 ga[4], gw[4];
+    auto gload = [&](int kt) {
+        const int soff = kt * BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ga[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_voff[j], soff, 0));
+            gw[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff[j], soff, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(u32x4*)(base + lds_off[j]) = ga[j];
+            *(u32x4*)(base + 16384 + lds_off[j]) = gw[j];
+        }
+    };
+
+    f32x4 acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int frow = lane & 15;            // row inside a 16-row fragment
+    const int fq = lane >> 4;              // k-chunk inside a 32-deep k-step
+    const int fx = lane & 7;               // == (row & 7) for every fragment row this lane reads
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* As = smem + buf * 32768;
+        const char* Ws = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = (((ks * 4 + fq) ^ fx) << 4);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(As + (wm * 64 + t * 16 + frow) * 128 + coff);
+                wf[t] = *(const bf16x8*)(Ws + (wn * 64 + t * 16 + frow) * 128 + coff);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: two 64-row halves through LDS ----------------
+    float* Cs = (float*)smem;
+    const int er = tid >> 5;              // 0..7 : row inside an 8-row pass
+    const int ec = (tid & 31) * 4;        // first of this thread's 4 columns
+    const int n = col0 + ec;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && n < p.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    int ml = tm * 16 + frow;
+                    int nl = wn * 64 + tn * 16 + fq * 4;
+                    *(f32x4*)(Cs + ml * CS_LD + nl) = acc[tn][tm];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int ml = pass * 8 + er;
+            const int m = row0 + half * 64 + ml;
+            if (m < p.M && n < p.N) {
+                f32x4 v = *(const f32x4*)(Cs + ml * CS_LD + ec);
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = v[j] + bias4[j];
+                if (EPI == EPI_BIAS_GELU) {
+                    u32x2 u2;
+                    u2[0] = pack2(o[0], o[1]);
+                    u2[1] = pack2(o[2], o[3]);
+                    *(u32x2*)(p.C2 + (size_t)m * p.ldc2 + n) = u2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
+                } else if (EPI == EPI_GATED_RES) {
+                    const int rr = p.r_mod > 0 ? (m % p.r_mod) : m;
+                    u32x2 r2 = *(const u32x2*)(p.R + (size_t)rr * p.ldr + n);
+                    float r[4] = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
+                                  __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
+                    if (p.gate_vid != nullptr) {
+                        const int b = m / p.S;
+                        const int s = m - b * p.S;
+                        const float* g = (s < p.St ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride + n;
+                        f32x4 g4 = *(const f32x4*)g;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = r[j] + g4[j] * o[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = r[j] + o[j];
+                    }
+                } else if (EPI == EPI_DGELU) {
+                    u32x2 u2 = *(const u32x2*)(p.U + (size_t)m * p.ldu + n);
+                    float u[4] = {__uint_as_float(u2[0] << 16), __uint_as_float(u2[0] & 0xffff0000u),
+                                  __uint_as_float(u2[1] << 16), __uint_as_float(u2[1] & 0xffff0000u)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = o[j] * gelu_tanh_grad_f(u[j]);
+                }
+                if (OUT_F32) {
+                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    u32x2 c2;
+                    c2[0] = pack2(o[0], o[1]);
+                    c2[1] = pack2(o[2], o[3]);
+                    *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = c2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int EPI, bool F32>
+static int launch(const GemmParams& p, hipStream_t st) {
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_tn_kernel<EPI, F32>), dim3(nbm * nbn), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                            int M, int N, int K, const void* bias, int epilogue, int out_fp32,
+                            const void* R, int ldr, int r_mod,
+                            const float* gate_txt, const float* gate_vid, int gate_bstride, int S, int St,
+                            void* C2, int ldc2, const void* U, int ldu, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return VT_ERR_BAD_SHAPE;
+    if ((lda % 8) || (ldw % 8) || (ldc % 4) || lda < K || ldw < K || ldc < N) return VT_ERR_BAD_SHAPE;
+    if (!al16(A) || !al16(W) || !al16(C)) return VT_ERR_BAD_ALIGN;
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = (const bf16_t*)bias;
+    p.R = (const bf16_t*)R; p.gate_txt = gate_txt; p.gate_vid = gate_vid;
+    p.C2 = (bf16_t*)C2; p.U = (const bf16_t*)U;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldc2 = ldc2; p.ldu = ldu;
+    p.S = S > 0 ? S : 1; p.St = St; p.gate_bstride = gate_bstride; p.r_mod = r_mod;
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case EPI_BIAS:
+            return out_fp32 ? launch<EPI_BIAS, true>(p, st) : launch<EPI_BIAS, false>(p, st);
+        case EPI_BIAS_GELU:
+            if (out_fp32 || C2 == nullptr || (ldc2 % 4) || !al16(C2)) return VT_ERR_BAD_SHAPE;
+            return launch<EPI_BIAS_GELU, false>(p, st);
+        case EPI_GATED_RES:
+            if (out_fp32 || R == nullptr || (ldr % 4) || !al16(R)) return VT_ERR_BAD_SHAPE;
+            if (gate_vid != nullptr && (gate_txt == nullptr || (gate_bstride % 4) || !al16(gate_vid) || !al16(gate_txt)))
+                return VT_ERR_BAD_SHAPE;
+            return launch<EPI_GATED_RES, false>(p, st);
+        case EPI_DGELU:
+            if (out_fp32 || U == nullptr || (ldu % 4) || !al16(U)) return VT_ERR_BAD_SHAPE;
+            return launch<EPI_DGELU, false>(p, st);
+        default:
+            return VT_ERR_UNSUPPORTED;
+    }
+}

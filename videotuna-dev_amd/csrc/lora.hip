@@ -1,0 +1,183 @@
+// LoRA side-path kernels (rank <= 16).  Semantics follow peft 0.12 LoraLayer as injected by the
+// reference at videotuna/models/cogvideo_hf/cogvideo_pl.py:143-149 with configs/004_cogvideox/cogvideo2b.yaml:32-38:
+//     y = W x + b + (alpha/r) * B (A x)
+// The engine folds the up-projection into the base GEMM by extending K: the activation buffer carries
+// T = x A^T in 16 extra columns and the weight carries (alpha/r) * B there, so forward and dX need no
+// special GEMM; these kernels produce T, the rank-r gradients, and the rank-r correction of dX.
+#include "common.h"
+
+// ---------------- T[M,16] = X[M,K] * A[R,K]^T  (R <= 16 rows valid, rest zero) -> bf16 ----------------
+// one wave per 16 rows, v_mfma_f32_16x16x32_bf16; each lane streams 32 contiguous bytes of its row per
+// 64-deep K block so every row is read in full 128-byte lines.
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* X, int ldx, const bf16_t* A, int lda, int R,
+                                                       bf16_t* T, int ldt, long long M, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    if (row0 >= M) return;
+    const int fr = lane & 15, fq = lane >> 4;
+    long long xr = row0 + fr;
+    if (xr > M - 1) xr = M - 1;
+    const bf16_t* xp = X + (size_t)xr * ldx + 16 * fq;
+    const bool aok = fr < R;
+    const bf16_t* ap = A + (size_t)(aok ? fr : 0) * lda + 16 * fq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; k += 64) {
+        bf16x8 x0 = *(const bf16x8*)(xp + k), x1 = *(const bf16x8*)(xp + k + 8);
+        bf16x8 a0 = aok ? *(const bf16x8*)(ap + k) : zero;
+        bf16x8 a1 = aok ? *(const bf16x8*)(ap + k + 8) : zero;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, a0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, a1, acc, 0, 0, 0);
+    }
+    // D[row = 4*fq + reg][col = fr]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long m = row0 + 4 * fq + j;
+        if (m < M) T[(size_t)m * ldt + fr] = f2bf(acc[j]);
+    }
+}
+extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,
+                            void* stream) {
+    if (M <= 0 || K <= 0 || (K % 64) || R <= 0 || R > 16 || (ldx % 8) || (lda % 8) || ldt < 16) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)X) | ((uintptr_t)A)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long blocks = (M + 63) / 64;
+    hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
+                       (const bf16_t*)A, lda, R, (bf16_t*)T, ldt, M, K);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ---------------- out[p*osp + r*osr] += alpha * sum_m Big[m,p] * Small[m,r]   (fp32 atomics) ----------------
+// Thread = 4 consecutive columns p, RR accumulators each; block = 1024 columns x 128 rows of m.
+#define SK_ROWS 128
+template <int RR>
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
+                                                       float* out, long long osp, long long osr, float alpha,
+                                                       long long M, int P) {
+    __shared__ __attribute__((aligned(16))) float sm[SK_ROWS * RR];
+    const long long m0 = (long long)blockIdx.y * SK_ROWS;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // stage Small[m0 .. m0+127][0..RR) as fp32 (zero past M or past R)
+    for (int i = threadIdx.x; i < SK_ROWS * RR; i += 256) {
+        const int mm = i / RR, rr = i - mm * RR;
+        const long long m = m0 + mm;
+        sm[i] = (m < M && rr < R) ? bf2f(Small[(size_t)m * lds_ + rr]) : 0.f;
+    }
+    __syncthreads();
+    if (p >= P) return;
+    float acc[4][RR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) acc[c][rr] = 0.f;
+    const int rows = (int)((M - m0) < SK_ROWS ? (M - m0) : SK_ROWS);
+    const bf16_t* bp = Big + (size_t)m0 * ldb + p;
+#pragma unroll 4
+    for (int mm = 0; mm < rows; ++mm) {
+        u32x2 raw = *(const u32x2*)(bp + (size_t)mm * ldb);
+        const float b0 = __uint_as_float(raw[0] << 16), b1 = __uint_as_float(raw[0] & 0xffff0000u);
+        const float b2 = __uint_as_float(raw[1] << 16), b3 = __uint_as_float(raw[1] & 0xffff0000u);
+#pragma unroll
+        for (int r4 = 0; r4 < RR / 4; ++r4) {
+            f32x4 s = *(const f32x4*)(sm + mm * RR + 4 * r4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][4 * r4 + j] += b0 * s[j];
+                acc[1][4 * r4 + j] += b1 * s[j];
+                acc[2][4 * r4 + j] += b2 * s[j];
+                acc[3][4 * r4 + j] += b3 * s[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr)
+            if (rr < R) atomicAdd(out + (size_t)(p + c) * osp + (size_t)rr * osr, alpha * acc[c][rr]);
+}
+extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
+                            long long osr, float alpha, long long M, int P, void* stream) {
+    if (M <= 0 || P <= 0 || (P % 4) || R <= 0 || R > 16 || (ldb % 4)) return VT_ERR_BAD_SHAPE;
+    if (((uintptr_t)Big) & 7) return VT_ERR_BAD_ALIGN;
+    dim3 grid((P + 1023) / 1024, (unsigned)((M + SK_ROWS - 1) / SK_ROWS));
+    hipStream_t st = (hipStream_t)stream;
+    if (R <= 4)
+        hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)Big, ldb, (const bf16_t*)Small, lds_, R, out,
+                           osp, osr, alpha, M, P);
+    else
+        hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(256), 0, st, (const bf16_t*)Big, ldb, (const bf16_t*)Small, lds_, R, out,
+                           osp, osr, alpha, M, P);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ---------------- dX[m,k] += sum_r dT[m,r] * A[r,k]   (in place, bf16) ----------------
+__global__ __launch_bounds__(256) void lora_up_add_kernel(bf16_t* dX, int ldx, const bf16_t* dT, int ldt, const bf16_t* A, int lda,
+                                                         int R, long long M, int K) {
+    const int nch = K >> 3;
+    const long long total = M * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch);
+        float v[8];
+        unpack8(*(const u32x4*)(dX + (size_t)m * ldx + c * 8), v);
+        for (int r = 0; r < R; ++r) {
+            const float t = bf2f(dT[(size_t)m * ldt + r]);
+            float a[8];
+            unpack8(*(const u32x4*)(A + (size_t)r * lda + c * 8), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += t * a[j];
+        }
+        *(u32x4*)(dX + (size_t)m * ldx + c * 8) = pack8(v);
+    }
+}
+extern "C" int vt_lora_up_add(void* dX, int ldx, const void* dT, int ldt, const void* A, int lda, int R, long long M, int K,
+                              void* stream) {
+    if (M <= 0 || K <= 0 || (K % 8) || R <= 0 || R > 16 || (ldx % 8) || (lda % 8)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)dX) | ((uintptr_t)A)) & 15) return VT_ERR_BAD_ALIGN;
+    long long total = M * (K >> 3), b = (total + 255) / 256;
+    hipLaunchKernelGGL(lora_up_add_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dX, ldx,
+                       (const bf16_t*)dT, ldt, (const bf16_t*)A, lda, R, M, K);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ---------------- write (alpha/r) * B[n, r] into the K-extension columns of the packed weight ----------------
+// Bcat: [n_adapters * d_out, r] fp32 master (adapter j = rows [j*d_out, (j+1)*d_out)); Wext points at column K of the
+// packed weight [n_adapters*d_out, ldw]; adapter j owns extension columns [j*r, (j+1)*r); the rest of the
+// 64-column extension stays zero.
+__global__ void lora_pack_b_kernel(const float* Bcat, bf16_t* Wext, int ldw, int n_adapters, int d_out, int r, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = n_adapters * d_out * 64;
+    if (i >= total) return;
+    const int n = i >> 6, c = i & 63;
+    const int j = n / d_out;
+    float v = 0.f;
+    if (c >= j * r && c < (j + 1) * r) v = scale * Bcat[(size_t)n * r + (c - j * r)];
+    Wext[(size_t)n * ldw + c] = f2bf(v);
+}
+extern "C" int vt_lora_pack_b(const float* Bcat, void* Wext, int ldw, int n_adapters, int d_out, int r, float scale,
+                              void* stream) {
+    if (n_adapters <= 0 || d_out <= 0 || r <= 0 || n_adapters * r > 16) return VT_ERR_BAD_SHAPE;
+    const int total = n_adapters * d_out * 64;
+    hipLaunchKernelGGL(lora_pack_b_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Bcat, (bf16_t*)Wext, ldw,
+                       n_adapters, d_out, r, scale);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// same for the transposed packed weight used by dX = dY * W:  WT is [K + 64, N]; rows K.. hold (alpha/r) * B^T
+__global__ void lora_pack_bt_kernel(const float* Bcat, bf16_t* WText, int ldwt, int n_adapters, int d_out, int r, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int N = n_adapters * d_out;
+    if (i >= 64 * N) return;
+    const int c = i / N, n = i - c * N;
+    const int j = n / d_out;
+    float v = 0.f;
+    if (c >= j * r && c < (j + 1) * r) v = scale * Bcat[(size_t)n * r + (c - j * r)];
+    WText[(size_t)c * ldwt + n] = f2bf(v);
+}
+extern "C" int vt_lora_pack_bt(const float* Bcat, void* WText, int ldwt, int n_adapters, int d_out, int r, float scale,
+                               void* stream) {
+    if (n_adapters <= 0 || d_out <= 0 || r <= 0 || n_adapters * r > 16) return VT_ERR_BAD_SHAPE;
+    const int total = n_adapters * d_out * 64;
+    hipLaunchKernelGGL(lora_pack_bt_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, Bcat, (bf16_t*)WText, ldwt,
+                       n_adapters, d_out, r, scale);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -1,0 +1,213 @@
+"""Thin tensor-level wrappers over the C-ABI (include/vt355.h).
+
+PyTorch is used here for device memory and streams only: every wrapper turns tensors into raw
+pointers / leading dimensions and launches the HIP kernel on torch's current stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from ._lib import check, load_library
+
+BF16 = torch.bfloat16
+EPI_BIAS, EPI_BIAS_GELU, EPI_GATED_RES, EPI_DGELU = 0, 1, 2, 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (the vt355 ops have no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim}-d, got shape {tuple(t.shape)}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost stride must be 1")
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.dim() == 2 else t.stride(-2)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+         epilogue: int = EPI_BIAS, residual: Optional[torch.Tensor] = None, r_mod: int = 0,
+         gate_txt: Optional[torch.Tensor] = None, gate_vid: Optional[torch.Tensor] = None, gate_bstride: int = 0,
+         S: int = 1, St: int = 0, pre_act_out: Optional[torch.Tensor] = None,
+         pre_act_in: Optional[torch.Tensor] = None, K: Optional[int] = None, N: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ epilogue).  a, w are 2-d (row-strided views allowed)."""
+    _req(a, BF16, "a", 2); _req(w, BF16, "w", 2)
+    M = a.shape[0]
+    K = a.shape[1] if K is None else K
+    N = w.shape[0] if N is None else N
+    out_f32 = out.dtype == torch.float32
+    if not out_f32:
+        _req(out, BF16, "out", 2)
+    lib = load_library()
+    check(lib.vt_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                           M, N, K, _p(bias), epilogue, int(out_f32),
+                           _p(residual), 0 if residual is None else residual.stride(0), r_mod,
+                           _p(gate_txt), _p(gate_vid), gate_bstride, S, St,
+                           _p(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
+                           _p(pre_act_in), 0 if pre_act_in is None else pre_act_in.stride(0), _stream()),
+          "vt_gemm_bf16")
+    return out
+
+
+def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None):
+    """q,k,v,o: views whose element (b,s,h,d) is at base + b*bs + s*rs + h*64 + d; given as 3-d [B,S,>=H*64]."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _req(t, BF16, n, 3)
+    scale = 1.0 / math.sqrt(64) if scale is None else scale
+    lib = load_library()
+    check(lib.vt_attn_fwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), B, H, S,
+                               q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()),
+          "vt_attn_fwd_hd64")
+
+
+def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: int, scale: Optional[float] = None):
+    scale = 1.0 / math.sqrt(64) if scale is None else scale
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dk", dk), ("dv", dv)):
+        _req(t, BF16, n, 3)
+    _req(dq_f32, torch.float32, "dq_f32", 3)
+    lib = load_library()
+    check(lib.vt_attn_bwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
+                               lse2.data_ptr(), delta_ws.data_ptr(), dq_f32.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                               B, H, S,
+                               q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1),
+                               dq_f32.stride(1), dk.stride(1), dv.stride(1),
+                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+                               dq_f32.stride(0), dk.stride(0), dv.stride(0), scale, _stream()),
+          "vt_attn_bwd_hd64")
+
+
+def ln_modulate_fwd(x, y, gamma, beta, mod, mean, rstd, D: int, S: int, St: int, eps: float):
+    """mod: None or (shift_txt, scale_txt, shift_vid, scale_vid, bstride) fp32 views."""
+    _req(x, BF16, "x", 2); _req(y, BF16, "y", 2)
+    m = (None, None, None, None, 0) if mod is None else mod
+    lib = load_library()
+    check(lib.vt_ln_modulate_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _p(gamma), _p(beta),
+                                 _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]), m[4], _p(mean), _p(rstd),
+                                 x.shape[0], D, S, St, eps, _stream()), "vt_ln_modulate_fwd")
+
+
+def ln_modulate_bwd(dy, x, mean, rstd, gamma, scales, dres, dx, D: int, S: int, St: int):
+    """scales: None or (scale_txt, scale_vid, bstride)."""
+    _req(dy, BF16, "dy", 2); _req(x, BF16, "x", 2); _req(dx, BF16, "dx", 2)
+    sc = (None, None, 0) if scales is None else scales
+    lib = load_library()
+    check(lib.vt_ln_modulate_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                 _p(gamma), _p(sc[0]), _p(sc[1]), sc[2], _p(dres), 0 if dres is None else dres.stride(0),
+                                 dx.data_ptr(), dx.stride(0), x.shape[0], D, S, St, _stream()), "vt_ln_modulate_bwd")
+
+
+def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float):
+    _req(qkv, BF16, "qkv", 2); _req(out, BF16, "out", 2)
+    lib = load_library()
+    check(lib.vt_qk_layernorm_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), bq.data_ptr(),
+                                  gk.data_ptr(), bk.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.shape[0], H, eps,
+                                  _stream()), "vt_qk_layernorm_fwd")
+
+
+def qk_layernorm_bwd(dq_hat_f32, dk_hat, qkv, mean, rstd, gq, gk, dqkv, H: int):
+    _req(dq_hat_f32, torch.float32, "dq_hat", 2); _req(dk_hat, BF16, "dk_hat", 2)
+    lib = load_library()
+    check(lib.vt_qk_layernorm_bwd(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
+                                  qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), gq.data_ptr(), gk.data_ptr(),
+                                  dqkv.data_ptr(), dqkv.stride(0), qkv.shape[0], H, _stream()), "vt_qk_layernorm_bwd")
+
+
+def gate_mul(x, y, g_txt, g_vid, bstride: int, D: int, S: int, St: int):
+    _req(x, BF16, "x", 2); _req(y, BF16, "y", 2)
+    lib = load_library()
+    check(lib.vt_gate_mul(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), g_txt.data_ptr(), g_vid.data_ptr(), bstride,
+                          x.shape[0], D, S, St, _stream()), "vt_gate_mul")
+
+
+def silu(x, y):
+    _req(x, BF16, "x"); _req(y, BF16, "y")
+    check(load_library().vt_silu_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "vt_silu_bf16")
+
+
+def cast_f32_bf16(x, y):
+    _req(x, torch.float32, "x"); _req(y, BF16, "y")
+    check(load_library().vt_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "vt_cast_f32_bf16")
+
+
+def timestep_embedding(t, out, flip: bool = True, freq_shift: float = 0.0):
+    _req(t, torch.int64, "t", 1); _req(out, BF16, "out", 2)
+    check(load_library().vt_timestep_embedding(t.data_ptr(), out.data_ptr(), out.shape[0], out.shape[1], int(flip),
+                                               freq_shift, _stream()), "vt_timestep_embedding")
+
+
+def patchify(img, tok, P: int):
+    _req(img, BF16, "img", 5); _req(tok, BF16, "tok", 2)
+    B, F, C, H, W = img.shape
+    check(load_library().vt_patchify(img.data_ptr(), tok.data_ptr(), B, F, C, H, W, P, tok.stride(0), _stream()), "vt_patchify")
+
+
+def unpatchify(tok, img, P: int):
+    _req(img, BF16, "img", 5); _req(tok, BF16, "tok", 2)
+    B, F, C, H, W = img.shape
+    check(load_library().vt_unpatchify(tok.data_ptr(), img.data_ptr(), B, F, C, H, W, P, tok.stride(0), _stream()),
+          "vt_unpatchify")
+
+
+def add_noise(x0, noise, sa, sb, noisy):
+    _req(x0, torch.float32, "x0"); _req(noise, torch.float32, "noise"); _req(noisy, BF16, "noisy")
+    B = x0.shape[0]
+    check(load_library().vt_add_noise(x0.data_ptr(), noise.data_ptr(), sa.data_ptr(), sb.data_ptr(), noisy.data_ptr(),
+                                      x0.numel() // B, B, _stream()), "vt_add_noise")
+
+
+def diffusion_loss(vpred, noisy, x0, sa, sb, w, loss, partials, dvpred, grad_scale: float = 1.0):
+    _req(vpred, BF16, "vpred"); _req(noisy, BF16, "noisy"); _req(x0, torch.float32, "x0")
+    B = x0.shape[0]
+    check(load_library().vt_diffusion_loss(vpred.data_ptr(), noisy.data_ptr(), x0.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                           w.data_ptr(), loss.data_ptr(), partials.data_ptr(), _p(dvpred),
+                                           x0.numel() // B, B, grad_scale, _stream()), "vt_diffusion_loss")
+
+
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0):
+    for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _req(t, torch.float32, n)
+    check(load_library().vt_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(),
+                                  lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "vt_adamw")
+
+
+def lora_down(x, a, R: int, t_out, K: int):
+    _req(x, BF16, "x", 2); _req(a, BF16, "a", 2); _req(t_out, BF16, "t", 2)
+    check(load_library().vt_lora_down(x.data_ptr(), x.stride(0), a.data_ptr(), a.stride(0), R, t_out.data_ptr(),
+                                      t_out.stride(0), x.shape[0], K, _stream()), "vt_lora_down")
+
+
+def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int):
+    _req(big, BF16, "big", 2); _req(small, BF16, "small", 2); _req(out, torch.float32, "out")
+    check(load_library().vt_skinny_tn(big.data_ptr(), big.stride(0), small.data_ptr(), small.stride(0), R, out.data_ptr(),
+                                      osp, osr, alpha, big.shape[0], P, _stream()), "vt_skinny_tn")
+
+
+def lora_up_add(dx, dt, a, R: int, K: int):
+    _req(dx, BF16, "dx", 2); _req(dt, BF16, "dt", 2); _req(a, BF16, "a", 2)
+    check(load_library().vt_lora_up_add(dx.data_ptr(), dx.stride(0), dt.data_ptr(), dt.stride(0), a.data_ptr(), a.stride(0),
+                                        R, dx.shape[0], K, _stream()), "vt_lora_up_add")
+
+
+def lora_pack_b(bcat_f32, wext, ldw: int, n_adapters: int, d_out: int, r: int, scale: float):
+    check(load_library().vt_lora_pack_b(bcat_f32.data_ptr(), wext.data_ptr(), ldw, n_adapters, d_out, r, scale, _stream()),
+          "vt_lora_pack_b")
+
+
+def lora_pack_bt(bcat_f32, wtext, ldwt: int, n_adapters: int, d_out: int, r: int, scale: float):
+    check(load_library().vt_lora_pack_bt(bcat_f32.data_ptr(), wtext.data_ptr(), ldwt, n_adapters, d_out, r, scale, _stream()),
+          "vt_lora_pack_bt")

@@ -115,6 +115,11 @@ int vt_diffusion_loss(const void* vpred, const void* noisy, const float* x0, con
                       const float* sqrt_1mab, const float* weights, float* loss, float* partials_ws,
                       void* dvpred, long long per_sample, int B, float grad_scale, void* stream);
 
+/* d loss / d v = grad_out[0] * 2 w_b (x0_hat - x0) (-sqrt_1mab) / (per_sample*B); grad_out is a DEVICE scalar */
+int vt_diffusion_loss_bwd(const void* vpred, const void* noisy, const float* x0, const float* sqrt_ab,
+                          const float* sqrt_1mab, const float* weights, const float* grad_out, void* dvpred,
+                          long long per_sample, int B, void* stream);
+
 /* torch.optim.AdamW step (cogvideo_pl.py:774-779) over one flat fp32 buffer; g is multiplied by grad_scale
  * first; p_bf16 (optional) receives the bf16 compute copy. step is 1-based. */
 int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
@@ -122,7 +127,7 @@ int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long lo
 
 /* LoRA (peft LoraLayer, cogvideo_pl.py:143-149) */
 int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,
-                 void* stream);                                  /* T[M,16] = X A^T                     */
+                 int zero_cols, void* stream);                   /* T[M,16] = X A^T ; T[:,16:16+zero_cols] = 0 */
 int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
                  long long osr, float alpha, long long M, int P, void* stream);
                                                                  /* out[p*osp+r*osr] += alpha*sum_m Big[m,p]*Small[m,r] */

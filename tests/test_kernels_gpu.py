@@ -249,7 +249,7 @@ def test_lora_kernels(dev):
     g = torch.Generator().manual_seed(9)
     M, K, N, r = 333, 128, 256, 4
     x = rb(torch.randn(M, K, generator=g)); A = rb(torch.randn(12, K, generator=g) * 0.1)
-    X = torch.zeros(M, K + 64, dtype=BF, device=dev); X[:, :K] = x.to(dev, BF)
+    X = torch.full((M, K + 64), float('nan'), dtype=BF, device=dev); X[:, :K] = x.to(dev, BF)
     ops.lora_down(X, A.to(dev, BF), 12, X[:, K:], K)
     close(X[:, K:K + 12], x @ A.T, 1e-2, 1e-2, "lora_down")
     assert X[:, K + 12:].abs().max().item() == 0.0

@@ -40,8 +40,9 @@ PROTOTYPES = {
     "vt_unpatchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "vt_add_noise": [_fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
     "vt_diffusion_loss": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _f, _vp],
+    "vt_diffusion_loss_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
     "vt_adamw": [_fp, _fp, _fp, _fp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp],
-    "vt_lora_down": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _vp],
+    "vt_lora_down": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _i, _vp],
     "vt_skinny_tn": [_vp, _i, _vp, _i, _i, _fp, _ll, _ll, _f, _ll, _i, _vp],
     "vt_lora_up_add": [_vp, _i, _vp, _i, _vp, _i, _i, _ll, _i, _vp],
     "vt_lora_pack_b": [_fp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -1,0 +1,53 @@
+"""``instantiate_from_config`` with the reference's semantics (videotuna/utils/common_utils.py:90-109): a node is
+``{target: dotted.path, params: {...}}``; targets under ``diffusers`` / ``transformers`` (or ``use_from_pretrained``)
+are built with ``Class.from_pretrained(**params)``.  Third-party targets that the reference's YAMLs name are mapped
+onto this engine's classes so ``configs/004_cogvideox/*.yaml`` load unchanged.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+from typing import Any
+
+TARGET_REMAP = {
+    "diffusers.CogVideoXTransformer3DModel": "vt355.dit.CogVideoXTransformer3DModel",
+    "diffusers.CogVideoXDPMScheduler": "vt355.scheduler.CogVideoXDPMScheduler",
+    "peft.LoraConfig": "vt355.lora.LoraConfig",
+    "videotuna.models.cogvideo_hf.cogvideo_pl.CogVideoXWorkFlow": "vt355.workflow.CogVideoXWorkFlow",
+}
+_NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
+
+
+def get_obj_from_str(string: str):
+    string = TARGET_REMAP.get(string, string)
+    module, cls = string.rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)
+
+
+def instantiate_from_config(config: Any, resolve=False):
+    if config is None:
+        return None
+    if "target" not in config:
+        if config in ("__is_first_stage__", "__is_unconditional__"):
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    target = config["target"]
+    params = dict(config.get("params", dict()) or {})
+    use_fp = bool(config.get("use_from_pretrained", False)) or "diffusers" in target or target.startswith("transformers")
+    cls = get_obj_from_str(target)
+    for k in _NON_CTOR_KEYS:
+        params.pop(k, None)
+    if use_fp and hasattr(cls, "from_pretrained") and "pretrained_model_name_or_path" in params:
+        path = params["pretrained_model_name_or_path"]
+        root = os.path.join(path, params.get("subfolder") or "")
+        if os.path.isdir(root):
+            return cls.from_pretrained(**params)
+        raise FileNotFoundError(f"{target}: local checkpoint directory {root!r} does not exist (no network access); "
+                                f"give explicit constructor params instead of pretrained_model_name_or_path")
+    return cls(**params)
+
+
+def load_yaml(path: str) -> dict:
+    import yaml
+    with open(path) as f:
+        return yaml.safe_load(f)

@@ -175,6 +175,27 @@ extern "C" int vt_diffusion_loss(const void* vpred, const void* noisy, const flo
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 
+// backward of the loss wrt the v-prediction; the upstream gradient is read from DEVICE memory (no host sync)
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const bf16_t* vpred, const bf16_t* noisy, const float* x0, const float* sa,
+                                                       const float* sb, const float* w, const float* gout, bf16_t* dv,
+                                                       long long per, int B) {
+    const long long n = per * B;
+    const float g = gout[0] * 2.0f / ((float)per * (float)B);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / per);
+        const float pred = sa[b] * bf2f(noisy[i]) - sb[b] * bf2f(vpred[i]);
+        dv[i] = f2bf(g * w[b] * (pred - x0[i]) * (-sb[b]));
+    }
+}
+extern "C" int vt_diffusion_loss_bwd(const void* vpred, const void* noisy, const float* x0, const float* sqrt_ab,
+                                     const float* sqrt_1mab, const float* weights, const float* grad_out, void* dvpred,
+                                     long long per_sample, int B, void* stream) {
+    if (per_sample <= 0 || B <= 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)vpred,
+                       (const bf16_t*)noisy, x0, sqrt_ab, sqrt_1mab, weights, grad_out, (bf16_t*)dvpred, per_sample, B);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
 // ---------------- fused AdamW over one flat fp32 buffer (+ bf16 compute copy) ----------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,

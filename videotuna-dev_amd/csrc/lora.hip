@@ -10,7 +10,7 @@
 // one wave per 16 rows, v_mfma_f32_16x16x32_bf16; each lane streams 32 contiguous bytes of its row per
 // 64-deep K block so every row is read in full 128-byte lines.
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* X, int ldx, const bf16_t* A, int lda, int R,
-                                                       bf16_t* T, int ldt, long long M, int K) {
+                                                       bf16_t* T, int ldt, long long M, int K, int zero_cols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long row0 = ((long long)blockIdx.x * 4 + wave) * 16;
     if (row0 >= M) return;
@@ -35,14 +35,20 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* X, int ldx
         const long long m = row0 + 4 * fq + j;
         if (m < M) T[(size_t)m * ldt + fr] = f2bf(acc[j]);
     }
+    // the rest of the K-extension must be exactly zero (the packed weight is zero there, but 0 * NaN is NaN)
+    for (int idx = lane; idx < 16 * zero_cols; idx += 64) {
+        const int rr = idx / zero_cols, cc = idx - rr * zero_cols;
+        if (row0 + rr < M) T[(size_t)(row0 + rr) * ldt + 16 + cc] = f2bf(0.f);
+    }
 }
 extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,
-                            void* stream) {
-    if (M <= 0 || K <= 0 || (K % 64) || R <= 0 || R > 16 || (ldx % 8) || (lda % 8) || ldt < 16) return VT_ERR_BAD_SHAPE;
+                            int zero_cols, void* stream) {
+    if (M <= 0 || K <= 0 || (K % 64) || R <= 0 || R > 16 || (ldx % 8) || (lda % 8) || ldt < 16 + zero_cols || zero_cols < 0)
+        return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)X) | ((uintptr_t)A)) & 15) return VT_ERR_BAD_ALIGN;
     const long long blocks = (M + 63) / 64;
     hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
-                       (const bf16_t*)A, lda, R, (bf16_t*)T, ldt, M, K);
+                       (const bf16_t*)A, lda, R, (bf16_t*)T, ldt, M, K, zero_cols);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

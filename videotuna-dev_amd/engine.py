@@ -1,0 +1,310 @@
+"""Forward / backward schedule of the CogVideoX DiT on the HIP kernels (the hot loop of SURVEY.md 3.1:
+``self.model(...)`` at videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871 and the ``loss.backward()`` PL runs on it).
+
+One autograd node covers the whole network: the forward launches the kernels and keeps the per-block
+activations the backward needs (no per-block recomputation -- 288 GB of HBM holds ~27 GB/sample);
+the backward walks the blocks in reverse, accumulates the LoRA gradients straight into the flat fp32 gradient
+buffer (``+=`` semantics, so gradient accumulation over micro-batches is native) and returns no tensor grads.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_GATED_RES
+
+EXT = 64
+
+
+def _lin(mod):
+    """(weight, bias) of a Linear holder or of a LoRA-wrapped one."""
+    base = getattr(mod, "base_layer", mod)
+    return base.weight, base.bias
+
+
+# ---------------------------------------------------------------------------------------------------
+# operand packing
+# ---------------------------------------------------------------------------------------------------
+def _ext_rows(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] -> [N,K+EXT] with a zero K-extension."""
+    out = torch.zeros(w.shape[0], w.shape[1] + EXT, dtype=BF16, device=w.device)
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def _ext_t(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] -> transposed [K+EXT,N] with zero extension rows."""
+    out = torch.zeros(w.shape[1] + EXT, w.shape[0], dtype=BF16, device=w.device)
+    out[:w.shape[1]] = w.t()
+    return out
+
+
+def pack(model) -> SimpleNamespace:
+    if any(p.requires_grad for n, p in model.named_parameters() if "lora" not in n):
+        raise NotImplementedError("full fine-tuning of the base weights is not built yet in this engine "
+                                  "(LoRA finetune is); freeze the base with requires_grad_(False)")
+    for n, p in model.named_parameters():
+        if "lora" not in n and p.dtype != BF16:
+            raise TypeError(f"parameter {n} is {p.dtype}; the MI355X engine computes in bf16 -- call .bfloat16()")
+    P = SimpleNamespace(layers=[], lora_version=-1)
+    with torch.no_grad():
+        for blk in model.transformer_blocks:
+            a = blk.attn1
+            wq, bq = _lin(a.to_q); wk, bk = _lin(a.to_k); wv, bv = _lin(a.to_v); wo, bo = _lin(a.to_out[0])
+            wqkv = torch.cat([wq, wk, wv], 0)
+            L = SimpleNamespace()
+            L.w_qkv = _ext_rows(wqkv); L.b_qkv = torch.cat([bq, bk, bv]).contiguous(); L.w_qkv_t = _ext_t(wqkv)
+            L.w_o = _ext_rows(wo); L.b_o = bo; L.w_o_t = _ext_t(wo)
+            w1, b1 = _lin(blk.ff.net[0].proj); w2, b2 = _lin(blk.ff.net[2])
+            L.w1, L.b1, L.w1_t = w1, b1, w1.t().contiguous()
+            L.w2, L.b2, L.w2_t = w2, b2, w2.t().contiguous()
+            L.n1g, L.n1b = blk.norm1.norm.weight, blk.norm1.norm.bias
+            L.n2g, L.n2b = blk.norm2.norm.weight, blk.norm2.norm.bias
+            L.gq, L.bq, L.gk, L.bk = a.norm_q.weight, a.norm_q.bias, a.norm_k.weight, a.norm_k.bias
+            P.layers.append(L)
+        ada_w = [m.linear.weight for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
+        ada_b = [m.linear.bias for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
+        P.w_ada = torch.cat(ada_w + [model.norm_out.linear.weight], 0).contiguous()
+        P.b_ada = torch.cat(ada_b + [model.norm_out.linear.bias], 0).contiguous()
+        pw = model.patch_embed.proj.weight
+        P.patch_w = pw.reshape(pw.shape[0], -1).contiguous()            # [d, C*p*p]  (c p q)
+        P.patch_b = model.patch_embed.proj.bias
+        P.text_w, P.text_b = _lin(model.patch_embed.text_proj)
+        P.t1_w, P.t1_b = _lin(model.time_embedding.linear_1)
+        P.t2_w, P.t2_b = _lin(model.time_embedding.linear_2)
+        P.proj_w, P.proj_b = _lin(model.proj_out)
+        P.proj_w_t = P.proj_w.t().contiguous()                          # [d, C*p*p]
+    return P
+
+
+def packed(model) -> SimpleNamespace:
+    if model._packed is None:
+        model._packed = pack(model)
+    P = model._packed
+    st = model.lora
+    if st is not None and P.lora_version != st.version:
+        d, r = model.inner_dim, st.r
+        for i, L in enumerate(P.layers):
+            ops.lora_pack_b(st.b_qkv(st.flat, i), L.w_qkv[:, d:], d + EXT, 3, d, r, st.scaling)
+            ops.lora_pack_bt(st.b_qkv(st.flat, i), L.w_qkv_t[d:], 3 * d, 3, d, r, st.scaling)
+            ops.lora_pack_b(st.b_out(st.flat, i), L.w_o[:, d:], d + EXT, 1, d, r, st.scaling)
+            ops.lora_pack_bt(st.b_out(st.flat, i), L.w_o_t[d:], d, 1, d, r, st.scaling)
+        P.lora_version = st.version
+    return P
+
+
+def _mod(mod: torch.Tensor, idx: int, d: int):
+    """six fp32 views into the modulation table for LayerNormZero number idx: chunk order
+    shift, scale, gate, enc_shift, enc_scale, enc_gate (video first, then text)."""
+    o = idx * 6 * d
+    v = lambda k: mod[:, o + k * d:]
+    return SimpleNamespace(shift_vid=v(0), scale_vid=v(1), gate_vid=v(2), shift_txt=v(3), scale_txt=v(4), gate_txt=v(5),
+                           bs=mod.stride(0))
+
+
+# ---------------------------------------------------------------------------------------------------
+def run_forward(model, x, text, t, save: bool):
+    c = model.config
+    P = packed(model)
+    st = model.lora
+    d, H, L = model.inner_dim, c.num_attention_heads, c.num_layers
+    B, Fr, C, Hh, Ww = x.shape
+    p = c.patch_size
+    Sv, St = Fr * (Hh // p) * (Ww // p), text.shape[1]
+    S = St + Sv
+    M = B * S
+    dev = x.device
+    KE = d + EXT if st is not None else d        # GEMM reduction length on the LoRA-extended operands
+    r3 = 3 * st.r if st is not None else 0
+    E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+
+    # ---- time embedding + every adaLN modulation of the network in one GEMM ----
+    te = c.time_embed_dim
+    tsin = E(B, d); ops.timestep_embedding(t, tsin, c.flip_sin_to_cos, float(c.freq_shift))
+    e1 = E(B, te); ops.gemm(tsin, P.t1_w, e1, P.t1_b)
+    ops.silu(e1, e1)
+    emb = E(B, te); ops.gemm(e1, P.t2_w, emb, P.t2_b)
+    ops.silu(emb, emb)                                    # every consumer applies SiLU(emb) first
+    mod = E(B, P.w_ada.shape[0], dt=torch.float32); ops.gemm(emb, P.w_ada, mod, P.b_ada)
+
+    # ---- patch / text embedding into the joint [text, video] sequence ----
+    h = E(M, d)
+    patches = E(B * Sv, C * p * p); ops.patchify(x, patches, p)
+    pos = model.pos_table(Fr, Hh, Ww, dev)
+    for b in range(B):
+        ops.gemm(patches[b * Sv:(b + 1) * Sv], P.patch_w, h[b * S + St:(b + 1) * S], P.patch_b,
+                 epilogue=EPI_GATED_RES, residual=pos)
+        ops.gemm(text[b], P.text_w, h[b * S:b * S + St], P.text_b)
+
+    saved: List[SimpleNamespace] = []
+    xg = E(M, d)                    # transient: norm2 output
+    gbuf = E(M, c.ff_mult * d)      # transient: GELU output
+    for i in range(L):
+        Lw = P.layers[i]
+        m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
+        a = SimpleNamespace(h_in=h)
+        # --- attention branch ---
+        x1 = E(M, d + EXT)
+        a.mean1, a.rstd1 = E(M, dt=torch.float32), E(M, dt=torch.float32)
+        ops.ln_modulate_fwd(h, x1, Lw.n1g, Lw.n1b, (m1.shift_txt, m1.scale_txt, m1.shift_vid, m1.scale_vid, m1.bs),
+                            a.mean1, a.rstd1, d, S, St, c.norm_eps)
+        if st is not None:
+            ops.lora_down(x1, st.a_qkv(st.flat_bf16, i), r3, x1[:, d:], d)
+        qkv = E(M, 3 * d)
+        ops.gemm(x1, Lw.w_qkv, qkv, Lw.b_qkv, K=KE)
+        qkh = E(M, 2 * d)
+        a.qmean, a.qrstd = E(M, 2 * H, dt=torch.float32), E(M, 2 * H, dt=torch.float32)
+        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6)
+        o = E(M, d + EXT)
+        lse = E(B, H, S, dt=torch.float32)
+        qk3, qkv3, o3 = qkh.view(B, S, 2 * d), qkv.view(B, S, 3 * d), o.view(B, S, d + EXT)
+        ops.attn_fwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], o3[:, :, :d], lse, B, H, S)
+        if st is not None:
+            ops.lora_down(o, st.a_out(st.flat_bf16, i), st.r, o[:, d:], d)
+        h1 = E(M, d)
+        ops.gemm(o, Lw.w_o, h1, Lw.b_o, epilogue=EPI_GATED_RES, residual=h, gate_txt=m1.gate_txt, gate_vid=m1.gate_vid,
+                 gate_bstride=m1.bs, S=S, St=St, K=KE)
+        # --- feed-forward branch ---
+        a.mean2, a.rstd2 = E(M, dt=torch.float32), E(M, dt=torch.float32)
+        ops.ln_modulate_fwd(h1, xg, Lw.n2g, Lw.n2b, (m2.shift_txt, m2.scale_txt, m2.shift_vid, m2.scale_vid, m2.bs),
+                            a.mean2, a.rstd2, d, S, St, c.norm_eps)
+        u = E(M, c.ff_mult * d) if save else gbuf.new_empty(M, c.ff_mult * d)
+        ops.gemm(xg, Lw.w1, gbuf, Lw.b1, epilogue=EPI_BIAS_GELU, pre_act_out=u)
+        h2 = E(M, d)
+        ops.gemm(gbuf, Lw.w2, h2, Lw.b2, epilogue=EPI_GATED_RES, residual=h1, gate_txt=m2.gate_txt, gate_vid=m2.gate_vid,
+                 gate_bstride=m2.bs, S=S, St=St)
+        if save:
+            a.x1, a.qkv, a.qkh, a.o, a.lse, a.h1, a.u = x1, qkv, qkh, o, lse, h1, u
+            saved.append(a)
+        h = h2
+
+    # ---- final: norm_final (video rows) -> AdaLayerNorm(shift, scale) -> proj_out -> unpatchify ----
+    mo = 2 * L * 6 * d
+    f_shift, f_scale = mod[:, mo:], mod[:, mo + d:]
+    y1 = E(B * Sv, d); y2 = E(B * Sv, d)
+    fm1, fr1 = E(B * Sv, dt=torch.float32), E(B * Sv, dt=torch.float32)
+    fm2, fr2 = E(B * Sv, dt=torch.float32), E(B * Sv, dt=torch.float32)
+    for b in range(B):
+        rows = slice(b * Sv, (b + 1) * Sv)
+        ops.ln_modulate_fwd(h[b * S + St:(b + 1) * S], y1[rows], model.norm_final.weight, model.norm_final.bias, None,
+                            fm1[rows], fr1[rows], d, Sv, 0, c.norm_eps)
+    ops.ln_modulate_fwd(y1, y2, model.norm_out.norm.weight, model.norm_out.norm.bias,
+                        (f_shift, f_scale, f_shift, f_scale, mod.stride(0)), fm2, fr2, d, Sv, 0, c.norm_eps)
+    tok = E(B * Sv, P.proj_w.shape[0])
+    ops.gemm(y2, P.proj_w, tok, P.proj_b)
+    out = E(B, Fr, c.out_channels, Hh, Ww)
+    ops.unpatchify(tok, out, p)
+    ctx = None
+    if save:
+        ctx = SimpleNamespace(blocks=saved, mod=mod, h_last=h, y1=y1, fm1=fm1, fr1=fr1, fm2=fm2, fr2=fr2,
+                              dims=(B, Fr, C, Hh, Ww, S, St, Sv, M), f_scale=f_scale)
+    return out, ctx
+
+
+def run_backward(model, ctx, dout: torch.Tensor):
+    c = model.config
+    P = packed(model)
+    st = model.lora
+    d, H, L = model.inner_dim, c.num_attention_heads, c.num_layers
+    B, Fr, C, Hh, Ww, S, St, Sv, M = ctx.dims
+    p = c.patch_size
+    dev = dout.device
+    r = st.r
+    E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+    mod = ctx.mod
+
+    # ---- final layers ----
+    dtok = E(B * Sv, C * p * p); ops.patchify(dout, dtok, p)
+    dy2 = E(B * Sv, d); ops.gemm(dtok, P.proj_w_t, dy2, None)
+    dy1 = E(B * Sv, d)
+    ops.ln_modulate_bwd(dy2, ctx.y1, ctx.fm2, ctx.fr2, model.norm_out.norm.weight, (ctx.f_scale, ctx.f_scale, mod.stride(0)),
+                        None, dy1, d, Sv, 0)
+    dh = torch.zeros(M, d, dtype=BF16, device=dev)          # text rows of the last block get no gradient (2B)
+    for b in range(B):
+        rows = slice(b * Sv, (b + 1) * Sv)
+        ops.ln_modulate_bwd(dy1[rows], ctx.h_last[b * S + St:(b + 1) * S], ctx.fm1[rows], ctx.fr1[rows],
+                            model.norm_final.weight, None, None, dh[b * S + St:(b + 1) * S], d, Sv, 0)
+
+    # ---- transient buffers shared by all blocks ----
+    tg = E(M, d)
+    du = E(M, c.ff_mult * d)
+    dx2 = E(M, d)
+    dh1 = E(M, d)
+    dO = E(M, d + EXT)
+    dq = E(B, S, d, dt=torch.float32)
+    dkh = E(M, d)
+    dqkv = E(M, 3 * d)
+    dx1 = E(M, d + EXT)
+    delta = E(B * H * S, dt=torch.float32)
+    dh_in = E(M, d)
+    for i in reversed(range(L)):
+        Lw, a = P.layers[i], ctx.blocks[i]
+        m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
+        # --- feed-forward branch:  h2 = h1 + gate_ff * W2 gelu(W1 x2 + b1) ---
+        ops.gate_mul(dh, tg, m2.gate_txt, m2.gate_vid, m2.bs, d, S, St)
+        ops.gemm(tg, Lw.w2_t, du, None, epilogue=EPI_DGELU, pre_act_in=a.u)
+        ops.gemm(du, Lw.w1_t, dx2, None)
+        ops.ln_modulate_bwd(dx2, a.h1, a.mean2, a.rstd2, Lw.n2g, (m2.scale_txt, m2.scale_vid, m2.bs), dh, dh1, d, S, St)
+        # --- attention branch:  h1 = h + gate_msa * (Wo' [O | T2]) ---
+        ops.gate_mul(dh1, tg, m1.gate_txt, m1.gate_vid, m1.bs, d, S, St)
+        ops.gemm(tg, Lw.w_o_t, dO, None)                                  # [M, d+EXT]: dO | dT2
+        ops.skinny_tn(tg, a.o[:, d:], r, st.b_out(st.grad, i), r, 1, st.scaling, d)            # dB_o
+        ops.skinny_tn(a.o, dO[:, d:], r, st.a_out(st.grad, i), 1, d, 1.0, d)                   # dA_o
+        ops.lora_up_add(dO, dO[:, d:], st.a_out(st.flat_bf16, i), r, d)
+        dq.zero_()
+        qk3, qkv3 = a.qkh.view(B, S, 2 * d), a.qkv.view(B, S, 3 * d)
+        ops.attn_bwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], a.o.view(B, S, d + EXT)[:, :, :d],
+                     dO.view(B, S, d + EXT)[:, :, :d], a.lse, delta, dq, dkh.view(B, S, d),
+                     dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S)
+        ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H)
+        ops.gemm(dqkv, Lw.w_qkv_t, dx1, None)                             # [M, d+EXT]: dx1 | dT1
+        for j in range(3):
+            ops.skinny_tn(dqkv[:, j * d:], a.x1[:, d + j * r:], r, st.b_qkv(st.grad, i)[j * d:], r, 1, st.scaling, d)
+        ops.skinny_tn(a.x1, dx1[:, d:], 3 * r, st.a_qkv(st.grad, i), 1, d, 1.0, d)
+        ops.lora_up_add(dx1, dx1[:, d:], st.a_qkv(st.flat_bf16, i), 3 * r, d)
+        if i > 0:
+            ops.ln_modulate_bwd(dx1, a.h_in, a.mean1, a.rstd1, Lw.n1g, (m1.scale_txt, m1.scale_vid, m1.bs), dh1, dh_in,
+                                d, S, St)
+            dh, dh_in = dh_in, dh
+        ctx.blocks[i] = None        # release this block's activations
+    return None
+
+
+class _DiTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x, text, t):
+        out, saved = run_forward(model, x, text, t, save=True)
+        ctx.model, ctx.saved = model, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        run_backward(ctx.model, ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return None, None, None, None, None
+
+
+def dit_apply(model, hidden_states, encoder_hidden_states, timestep):
+    x = hidden_states
+    if x.dtype != BF16:
+        raise TypeError(f"hidden_states must be bf16 (model dtype), got {x.dtype}")
+    x = x.contiguous()
+    text = encoder_hidden_states
+    if text.dtype == torch.float32:
+        tb = torch.empty(text.shape, dtype=BF16, device=text.device)
+        ops.cast_f32_bf16(text.contiguous(), tb)
+        text = tb
+    text = text.contiguous()
+    if timestep.dim() == 0:
+        timestep = timestep[None].expand(x.shape[0])
+    t = timestep.to(torch.int64).contiguous()
+    st = model.lora
+    need_grad = torch.is_grad_enabled() and st is not None and any(p.requires_grad for p in st.params)
+    if not need_grad:
+        out, _ = run_forward(model, x, text, t, save=False)
+        return out
+    anchor = torch.zeros(1, device=x.device, requires_grad=True)
+    return _DiTFn.apply(anchor, model, x, text, t)

@@ -1,0 +1,229 @@
+"""LoRA injection with peft's surface (``peft.LoraConfig`` / ``peft.get_peft_model``), as used by the reference at
+videotuna/models/cogvideo_hf/cogvideo_pl.py:143-149 with configs/004_cogvideox/cogvideo2b.yaml:32-38
+(r=4, lora_alpha=1.0, target_modules to_k,to_q,to_v,to_out.0, init_lora_weights=True):
+
+    y = W x + b + (lora_alpha / r) * B(A(x)),   A ~ kaiming_uniform(a=sqrt 5),  B = 0,  base frozen.
+
+State-dict keys follow peft 0.12: ``base_model.model.<path>.base_layer.weight``,
+``base_model.model.<path>.lora_A.default.weight`` -- the reference only relies on the substring "lora"
+(cogvideo_pl.py:781-787, videotuna/utils/callbacks.py:44-46).
+
+All adapter weights live in ONE flat fp32 master buffer (plus a flat fp32 gradient buffer and a flat bf16 compute
+copy) so the optimizer is one fused kernel launch and data-parallel training needs one all-reduce.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+TARGETS = ("to_q", "to_k", "to_v", "to_out.0")
+
+
+@dataclass
+class LoraConfig:
+    r: int = 8
+    lora_alpha: float = 8
+    target_modules: Optional[Sequence[str]] = None
+    lora_dropout: float = 0.0
+    init_lora_weights: bool = True
+    bias: str = "none"
+    task_type: Optional[str] = None
+    extra: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if self.lora_dropout:
+            raise NotImplementedError("lora_dropout > 0 is not supported (the reference config uses 0)")
+        if self.bias != "none":
+            raise NotImplementedError("bias != 'none' is not supported")
+        if self.r <= 0 or self.r > 4:
+            raise NotImplementedError("the fused K-extension supports rank <= 4 per adapter (3 adapters x r <= 16)")
+
+
+class _W(nn.Module):
+    """holder whose only parameter is ``weight`` (so keys read ``lora_A.default.weight``)."""
+
+    def __init__(self, p: nn.Parameter):
+        super().__init__()
+        self.weight = p
+
+
+class LoraLinear(nn.Module):
+    def __init__(self, base: nn.Module, a: nn.Parameter, b: nn.Parameter, scaling: float):
+        super().__init__()
+        self.base_layer = base
+        self.lora_A = nn.ModuleDict({"default": _W(a)})
+        self.lora_B = nn.ModuleDict({"default": _W(b)})
+        self.scaling = {"default": scaling}
+        self.in_features, self.out_features = base.in_features, base.out_features
+
+    @property
+    def weight(self):
+        return self.base_layer.weight
+
+    @property
+    def bias(self):
+        return self.base_layer.bias
+
+
+class LoraState:
+    """Flat storage for every adapter of a DiT.  Per layer: A_qkv [3r,d] | A_o [r,d] | B_qkv [3d,r] | B_o [d,r]."""
+
+    def __init__(self, model, cfg: LoraConfig):
+        self.cfg = cfg
+        self.r = cfg.r
+        self.scaling = float(cfg.lora_alpha) / cfg.r
+        self.d = model.inner_dim
+        self.L = model.config.num_layers
+        tm = list(cfg.target_modules or TARGETS)
+        for t in tm:
+            if t not in TARGETS:
+                raise ValueError(f"unsupported LoRA target {t!r}; the attention projections {TARGETS} are supported")
+        self.targets = tm
+        r, d = self.r, self.d
+        self.per_layer = 8 * r * d
+        dev = model.device
+        self.flat = torch.zeros(self.L * self.per_layer, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.flat)
+        self.flat_bf16 = torch.zeros(self.L * self.per_layer, dtype=torch.bfloat16, device=dev)
+        self.version = 0              # bumped whenever the master weights change (optimizer step / load)
+        self.params: List[nn.Parameter] = []
+
+    # offsets inside one layer's slab
+    def off_A(self, j):       # j: 0..2 = q,k,v ; 3 = out
+        return j * self.r * self.d
+    def off_B(self, j):
+        return 4 * self.r * self.d + j * self.d * self.r
+
+    def view(self, buf, layer, kind, j):
+        o = layer * self.per_layer + (self.off_A(j) if kind == "A" else self.off_B(j))
+        n = self.r * self.d
+        return buf[o:o + n].view((self.r, self.d) if kind == "A" else (self.d, self.r))
+
+    def a_qkv(self, buf, layer):      # [3r, d] contiguous (q,k,v adapters stacked)
+        o = layer * self.per_layer
+        return buf[o:o + 3 * self.r * self.d].view(3 * self.r, self.d)
+
+    def a_out(self, buf, layer):
+        o = layer * self.per_layer + 3 * self.r * self.d
+        return buf[o:o + self.r * self.d].view(self.r, self.d)
+
+    def b_qkv(self, buf, layer):      # [3d, r]
+        o = layer * self.per_layer + 4 * self.r * self.d
+        return buf[o:o + 3 * self.d * self.r].view(3 * self.d, self.r)
+
+    def b_out(self, buf, layer):
+        o = layer * self.per_layer + 7 * self.r * self.d
+        return buf[o:o + self.d * self.r].view(self.d, self.r)
+
+    def init(self, seed: int = 1):
+        g = torch.Generator().manual_seed(seed)
+        bound = 1.0 / math.sqrt(self.d)
+        host = torch.zeros(self.L * self.per_layer, dtype=torch.float32)
+        for layer in range(self.L):
+            for j, t in enumerate(TARGETS):
+                if t in self.targets:
+                    a = (torch.rand((self.r, self.d), generator=g) * 2 - 1) * bound
+                    o = layer * self.per_layer + self.off_A(j)
+                    host[o:o + a.numel()] = a.reshape(-1)
+        with torch.no_grad():
+            self.flat.copy_(host.to(self.flat.device))
+        self.mark_changed()
+
+    def mark_changed(self):
+        from . import ops
+        if self.flat.is_cuda:
+            ops.cast_f32_bf16(self.flat, self.flat_bf16)
+        self.version += 1
+
+    def attach_grads(self):
+        """Point every adapter Parameter's .grad at its slice of the flat gradient buffer."""
+        for p, (layer, kind, j) in zip(self.params, self._index):
+            p.grad = self.view(self.grad, layer, kind, j)
+
+    def on_module_moved(self):
+        # nn.Module._apply moved / converted the Parameters individually: re-home them into one flat buffer
+        if not self.params:
+            return
+        dev = self.params[0].device
+        new_flat = torch.zeros(self.L * self.per_layer, dtype=torch.float32, device=dev)
+        for p, (layer, kind, j) in zip(self.params, self._index):
+            self.view(new_flat, layer, kind, j).copy_(p.detach().to(torch.float32))
+        self.flat = new_flat
+        self.grad = torch.zeros_like(new_flat)
+        self.flat_bf16 = torch.zeros(new_flat.numel(), dtype=torch.bfloat16, device=dev)
+        for p, (layer, kind, j) in zip(self.params, self._index):
+            p.data = self.view(self.flat, layer, kind, j)
+        self.attach_grads()
+        self.mark_changed()
+
+
+def inject(model, cfg: LoraConfig, seed: int = 1) -> LoraState:
+    """Freeze the base model and wrap the targeted projections (in place)."""
+    st = LoraState(model, cfg)
+    st._index = []
+    for layer, blk in enumerate(model.transformer_blocks):
+        for j, t in enumerate(TARGETS):
+            if t not in st.targets:
+                continue
+            a = nn.Parameter(st.view(st.flat, layer, "A", j), requires_grad=True)
+            b = nn.Parameter(st.view(st.flat, layer, "B", j), requires_grad=True)
+            if t == "to_out.0":
+                base = blk.attn1.to_out[0]
+                blk.attn1.to_out[0] = LoraLinear(base, a, b, st.scaling)
+            else:
+                base = getattr(blk.attn1, t)
+                setattr(blk.attn1, t, LoraLinear(base, a, b, st.scaling))
+            st.params += [a, b]
+            st._index += [(layer, "A", j), (layer, "B", j)]
+    model.lora = st
+    if cfg.init_lora_weights:
+        st.init(seed)
+    st.attach_grads()
+    return st
+
+
+class _LoraModel(nn.Module):       # peft's ``base_model`` level
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, *a, **k):
+        return self.model(*a, **k)
+
+
+class PeftModel(nn.Module):
+    """Minimal stand-in for peft.PeftModel: same key prefix (``base_model.model.``) and attribute pass-through."""
+
+    def __init__(self, model, cfg: LoraConfig):
+        super().__init__()
+        model.requires_grad_(False)
+        self.peft_config = {"default": cfg}
+        state = inject(model, cfg)
+        self.base_model = _LoraModel(model)
+        self._lora_state = state
+
+    def forward(self, *a, **k):
+        return self.base_model(*a, **k)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.base_model.model, name)
+
+    def get_nb_trainable_parameters(self):
+        tr = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        al = sum(p.numel() for p in self.parameters())
+        return tr, al
+
+    def print_trainable_parameters(self):
+        tr, al = self.get_nb_trainable_parameters()
+        print(f"trainable params: {tr:,d} || all params: {al:,d} || trainable%: {100 * tr / al:.4f}")
+
+
+def get_peft_model(model, peft_config: LoraConfig) -> PeftModel:
+    return PeftModel(model, peft_config)

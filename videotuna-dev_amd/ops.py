@@ -178,6 +178,14 @@ def diffusion_loss(vpred, noisy, x0, sa, sb, w, loss, partials, dvpred, grad_sca
                                            x0.numel() // B, B, grad_scale, _stream()), "vt_diffusion_loss")
 
 
+def diffusion_loss_bwd(vpred, noisy, x0, sa, sb, w, grad_out, dvpred):
+    _req(grad_out, torch.float32, "grad_out")
+    B = x0.shape[0]
+    check(load_library().vt_diffusion_loss_bwd(vpred.data_ptr(), noisy.data_ptr(), x0.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                               w.data_ptr(), grad_out.data_ptr(), dvpred.data_ptr(), x0.numel() // B, B,
+                                               _stream()), "vt_diffusion_loss_bwd")
+
+
 def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0):
     for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _req(t, torch.float32, n)
@@ -185,10 +193,11 @@ def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: 
                                   lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "vt_adamw")
 
 
-def lora_down(x, a, R: int, t_out, K: int):
+def lora_down(x, a, R: int, t_out, K: int, zero_cols: int = 48):
+    """t_out[:, :16] = x[:, :K] @ a[:R]^T (zero past R); t_out[:, 16:16+zero_cols] = 0."""
     _req(x, BF16, "x", 2); _req(a, BF16, "a", 2); _req(t_out, BF16, "t", 2)
     check(load_library().vt_lora_down(x.data_ptr(), x.stride(0), a.data_ptr(), a.stride(0), R, t_out.data_ptr(),
-                                      t_out.stride(0), x.shape[0], K, _stream()), "vt_lora_down")
+                                      t_out.stride(0), x.shape[0], K, zero_cols, _stream()), "vt_lora_down")
 
 
 def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int):

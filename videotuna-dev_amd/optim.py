@@ -1,0 +1,79 @@
+"""Fused AdamW (torch.optim.AdamW semantics and defaults: betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2,
+decoupled decay) -- what ``configure_optimizers`` returns in the reference (cogvideo_pl.py:774-779).
+
+When the parameters are the adapter views of one ``LoraState`` the whole update is ONE kernel over the flat fp32
+master buffer (which also refreshes the flat bf16 compute copy); otherwise one launch per tensor.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+from . import ops
+
+
+class FusedAdamW:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, lora_state=None):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FusedAdamW keeps fp32 master weights; got a parameter of dtype %s" % p.dtype)
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        self.param_groups = [dict(params=self.params, **self.defaults)]
+        self.lora_state = lora_state
+        self.step_count = 0
+        if lora_state is not None:
+            if sum(p.numel() for p in self.params) != sum(p.numel() for p in lora_state.params):
+                raise ValueError("flat mode needs exactly the adapter parameters of the LoraState")
+            self.m = torch.zeros_like(lora_state.flat)
+            self.v = torch.zeros_like(lora_state.flat)
+        else:
+            self.m = [torch.zeros_like(p) for p in self.params]
+            self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self.lora_state is not None:
+            self.lora_state.grad.zero_()
+        else:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        self.step_count += 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        if self.lora_state is not None:
+            st = self.lora_state
+            ops.adamw(st.flat, st.grad, self.m, self.v, st.flat_bf16, g["lr"], b1, b2, g["eps"], g["weight_decay"],
+                      self.step_count, grad_scale)
+            st.version += 1            # packed K-extension columns are refreshed at the next forward
+        else:
+            for p, m, v in zip(self.params, self.m, self.v):
+                if p.grad is None:
+                    continue
+                ops.adamw(p.data, p.grad, m, v, None, g["lr"], b1, b2, g["eps"], g["weight_decay"], self.step_count,
+                          grad_scale)
+        return loss
+
+    def state_dict(self):
+        return dict(step=self.step_count, param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                    m=self.m if torch.is_tensor(self.m) else list(self.m), v=self.v if torch.is_tensor(self.v) else list(self.v))
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+        if torch.is_tensor(self.m):
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        else:
+            for a, b in zip(self.m, sd["m"]):
+                a.copy_(b)
+            for a, b in zip(self.v, sd["v"]):
+                a.copy_(b)

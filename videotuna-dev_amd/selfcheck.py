@@ -1,0 +1,95 @@
+"""One tiny end-to-end training step of the hot path on cuda:0, checked against the CPU oracle.
+Used by ``__graft_entry__.smoke()`` and by the GPU parity tests (the oracle is the checker, never the product)."""
+from __future__ import annotations
+
+import torch
+
+
+def build_tiny(device, layers=2, heads=2, seed=0, lora_b_random=True):
+    import cogvideox_oracle as O
+    from .dit import CogVideoXTransformer3DModel
+    from .lora import LoraConfig, get_peft_model
+    cfg = O.tiny_config(num_layers=layers, num_attention_heads=heads)
+    kw = {k: getattr(cfg, k) for k in ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers",
+                                       "time_embed_dim", "text_embed_dim", "patch_size", "sample_width", "sample_height",
+                                       "sample_frames", "max_text_seq_length")}
+    model = CogVideoXTransformer3DModel(**kw).init_weights(seed).to(device)
+    model.requires_grad_(False)
+    peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
+    st = peft._lora_state
+    if lora_b_random:          # B = 0 (peft init) would hide the adapters from the forward: randomise for the check
+        g = torch.Generator().manual_seed(seed + 7)
+        with torch.no_grad():
+            for p, (layer, kind, j) in zip(st.params, st._index):
+                if kind == "B":
+                    p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+        st.mark_changed()
+    return cfg, model, peft, st
+
+
+def oracle_params(model, st, dtype=torch.float32):
+    """bf16-rounded copies of the device weights, in the oracle's (HF) key layout."""
+    P = {}
+    for k, v in model.state_dict().items():
+        if "lora" in k:
+            continue
+        P[k.replace(".base_layer", "")] = v.detach().float().cpu().to(dtype)
+    Lo = {}
+    for p, (layer, kind, j) in zip(st.params, st._index):
+        name = ("to_q", "to_k", "to_v", "to_out.0")[j]
+        Lo[f"transformer_blocks.{layer}.attn1.{name}.lora_{kind}.default.weight"] = \
+            p.detach().to(torch.bfloat16).float().cpu().to(dtype)
+    return P, Lo
+
+
+def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2):
+    import cogvideox_oracle as O
+    from .scheduler import CogVideoXDPMScheduler
+    from .workflow import _LossFn
+    from .optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    cfg, model, peft, st = build_tiny(dev)
+    g = torch.Generator().manual_seed(123)
+    Fr = (cfg.sample_frames - 1) // 4 + 1
+    x0 = torch.randn(B, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g)
+    text = (torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g) * 0.5).to(torch.bfloat16)
+    noise = torch.randn(x0.shape, generator=g)
+    t = torch.tensor([200, 800][:B])
+    sched = CogVideoXDPMScheduler()
+    # ---- device path ----
+    noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
+    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev), return_dict=False)[0]
+    sa, sb, w = sched.coefficients(t.to(dev))
+    loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
+    st.grad.zero_()
+    loss.backward()
+    # ---- oracle (fp64 on the same bf16-rounded weights / inputs) ----
+    P, Lo = oracle_params(model, st, torch.float64)
+    for v in Lo.values():
+        v.requires_grad_(True)
+    abar = O.alphas_cumprod_cogvideox()
+    noisy_ref = noisy.float().cpu().double()
+    out_ref = O.dit_forward(P, cfg, noisy_ref, text.double(), t, Lo, st.scaling)
+    pred = O.get_velocity(out_ref, noisy_ref, t, abar)
+    wref = (1.0 / (1.0 - abar[t])).view(-1, 1, 1, 1, 1)
+    loss_ref = torch.mean((wref * (pred - x0.double()) ** 2).reshape(B, -1), dim=1).mean()
+    loss_ref.backward()
+    gref = torch.cat([Lo[k].grad.reshape(-1) for k in Lo])
+    gdev = torch.cat([st.view(st.grad, layer, kind, j).reshape(-1).cpu().double()
+                      for (layer, kind, j) in st._index])
+    out_err = (out.float().cpu().double() - out_ref).abs().max().item() / out_ref.abs().max().item()
+    loss_err = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    grad_err = (gdev - gref).norm().item() / gref.norm().item()
+    cos = torch.nn.functional.cosine_similarity(gdev, gref, dim=0).item()
+    if verbose:
+        print(f"[vt355 smoke] loss dev {loss.item():.6f} oracle {loss_ref.item():.6f} rel {loss_err:.2e}; "
+              f"out rel-max-err {out_err:.2e}; LoRA grad rel-L2 {grad_err:.2e} cos {cos:.5f}")
+    assert out_err < 5e-2, out_err
+    assert loss_err < tol_loss, (loss.item(), loss_ref.item())
+    assert grad_err < tol_grad and cos > 0.995, (grad_err, cos)
+    # one optimizer step must change the adapters and keep them finite
+    opt = FusedAdamW(st.params, lr=1e-3, lora_state=st)
+    before = st.flat.clone()
+    opt.step()
+    assert torch.isfinite(st.flat).all() and (st.flat - before).abs().max().item() > 0
+    return dict(loss=loss.item(), loss_ref=loss_ref.item(), out_err=out_err, grad_err=grad_err, cos=cos)

@@ -1,0 +1,119 @@
+"""``CogVideoXWorkFlow`` -- the training workflow of videotuna/models/cogvideo_hf/cogvideo_pl.py:90-149, 774-887 on the
+vt355 engine: same constructor keys (so configs/004_cogvideox/*.yaml load unchanged through
+``vt355.config.instantiate_from_config``), same ``training_step(batch, batch_idx) -> loss``,
+``configure_optimizers()``, ``inject_adapter()``, ``on_save_checkpoint()`` (LoRA-only filter), ``lora_args``.
+
+Scope: the frozen VAE and T5 encoders are NOT part of this hot path.  A batch is either
+  * pre-encoded: {"latents": [B,C,F,H,W] (VAE sample * scaling_factor), "prompt_embeds": [B,226,4096]}  or
+  * the reference schema {"video", "caption"} together with user-supplied ``first_stage`` / ``cond_stage`` callables.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import instantiate_from_config
+from .lora import LoraConfig, get_peft_model
+from .optim import FusedAdamW
+
+
+class _LossFn(torch.autograd.Function):
+    """loss = mean_b mean_i [ w_b (sqrt(abar) x_t - sqrt(1-abar) v - x0)^2 ]   (cogvideo_pl.py:872-886)."""
+
+    @staticmethod
+    def forward(ctx, vpred, noisy, x0, sa, sb, w):
+        loss = torch.empty(1, dtype=torch.float32, device=vpred.device)
+        part = torch.empty(512, dtype=torch.float32, device=vpred.device)
+        ops.diffusion_loss(vpred, noisy, x0, sa, sb, w, loss, part, None)
+        ctx.save_for_backward(vpred, noisy, x0, sa, sb, w)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        vpred, noisy, x0, sa, sb, w = ctx.saved_tensors
+        dv = torch.empty_like(vpred)
+        ops.diffusion_loss_bwd(vpred, noisy, x0, sa, sb, w, gout.reshape(1).to(torch.float32).contiguous(), dv)
+        return dv, None, None, None, None, None
+
+
+class CogVideoXWorkFlow(nn.Module):
+    def __init__(self, first_stage_config=None, cond_stage_config=None, denoiser_config=None, scheduler_config=None,
+                 learning_rate: float = 6e-6, adapter_config=None, logdir=None, first_stage=None, cond_stage=None):
+        super().__init__()
+        self.logdir = logdir
+        self.learning_rate = learning_rate
+        self.first_stage, self.cond_stage = first_stage, cond_stage       # optional frozen encoders (out of scope)
+        self.vae_scale_factor_spatial, self.vae_scale_factor_temporal = 8, 4
+        self.model = instantiate_from_config(denoiser_config)
+        params = denoiser_config.get("params", {}) if isinstance(denoiser_config, dict) else {}
+        # reference: load_dtype fp16 -> .half() (cogvideo_pl.py:125-132).  BASELINE fixes bf16 for this engine;
+        # fp16 requests are served in bf16 (documented deviation).
+        self.model.bfloat16()
+        self.scheduler = instantiate_from_config(scheduler_config)
+        self.lora_args = []
+        if adapter_config is not None:
+            self.inject_adapter(adapter_config)
+        self.model.enable_gradient_checkpointing()
+        self.global_step = 0
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def inject_adapter(self, adapter_config):
+        self.model.requires_grad_(False)
+        cfg = instantiate_from_config(adapter_config) if not isinstance(adapter_config, LoraConfig) else adapter_config
+        self.model = get_peft_model(self.model, cfg)
+        self.model.print_trainable_parameters()
+
+    def configure_optimizers(self):
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        st = getattr(self.model, "_lora_state", None)
+        return FusedAdamW(params, lr=self.learning_rate, lora_state=st)
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> Dict[str, Any]:
+        sd = {k: v for k, v in checkpoint["state_dict"].items() if "lora" in k}
+        if len(sd) > 0:
+            checkpoint["state_dict"] = sd
+        return checkpoint
+
+    def on_load_checkpoint(self, checkpoint):
+        pass
+
+    # ---- batch handling ----
+    def get_batch_input(self, batch):
+        if "latents" in batch:
+            return {"videos": batch["latents"], "prompt_embeds": batch["prompt_embeds"]}
+        if self.first_stage is None or self.cond_stage is None:
+            raise RuntimeError("batch has the reference schema {'video','caption'} but no frozen VAE / T5 encoder was given: "
+                               "they are outside this engine's hot path (SURVEY 8(f)); pass pre-encoded "
+                               "{'latents','prompt_embeds'} or construct the workflow with first_stage=/cond_stage= callables")
+        with torch.no_grad():
+            vids = torch.cat([self.first_stage(v) for v in batch["video"]], dim=0)
+            emb = self.cond_stage([c for c in batch["caption"]])
+        return {"videos": vids, "prompt_embeds": emb}
+
+    def training_step(self, batch, batch_idx=0):
+        b = self.get_batch_input(batch)
+        # [B,C,F,H,W] -> [B,F,C,H,W] (cogvideo_pl.py:817-819); the diffusion math runs in fp32, the DiT in bf16
+        x0 = b["videos"].permute(0, 2, 1, 3, 4).to(torch.float32).contiguous()
+        prompt_embeds = b["prompt_embeds"]
+        B = x0.shape[0]
+        noise = torch.randn_like(x0)
+        timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=x0.device).long()
+        return self.loss_from(x0, prompt_embeds, noise, timesteps)
+
+    def loss_from(self, x0, prompt_embeds, noise, timesteps):
+        """Deterministic core of training_step (fixed noise / t) -- what the parity tests call."""
+        noisy = self.scheduler.add_noise(x0, noise, timesteps)
+        out = self.model(hidden_states=noisy, encoder_hidden_states=prompt_embeds, timestep=timesteps,
+                         image_rotary_emb=None, return_dict=False)[0]
+        sa, sb, w = self.scheduler.coefficients(timesteps)
+        return _LossFn.apply(out, noisy, x0, sa, sb, w)

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- finetune samples/sec + step time, CogVideoX-2B T2V LoRA 49x480x720 bf16 (BASELINE.json metric).
+
+One "step" = one optimizer step of the reference recipe (configs/004_cogvideox/cogvideo2b.yaml: batch_size 2,
+accumulate_grad_batches 2): 2 micro-batches x 2 samples of synthetic latents [2,13,16,60,90] + text [2,226,4096]
+already resident in HBM -> add_noise -> DiT forward -> loss -> backward (LoRA grads) -> [DDP all-reduce] -> fused AdamW.
+Random-init weights of the 2B architecture (no checkpoints offline), nothing skipped inside the timed region.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def cpu_baseline(seconds_budget=40.0):
+    """The oracle (CPU restatement of the reference path) timed on the host cores: ONE full-size CogVideoX-2B block,
+    forward + backward, B=1, S=17776, fp32 eager; a sample needs 30 such blocks (embeddings/final < 0.1 % of FLOPs)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cogvideox_oracle as O
+    cfg = O.DiTConfig(num_layers=1)
+    torch.manual_seed(0)
+    P = {k: v for k, v in O.init_params(cfg, 0).items() if k.startswith("transformer_blocks.0.")}
+    Lo = O.init_lora(cfg, r=4, seed=1, zero_b=False)
+    for v in Lo.values():
+        v.requires_grad_(True)
+    St, Sv, d = 226, 17550, cfg.inner_dim
+    h_txt = torch.randn(1, St, d); h_vid = torch.randn(1, Sv, d).requires_grad_(True)   # dX must flow to earlier blocks
+    emb = torch.randn(1, cfg.time_embed_dim)
+    t0 = time.time()
+    ht, hv = O.dit_block(h_txt, h_vid, emb, P, "transformer_blocks.0.", cfg, Lo, 0.25)
+    (hv.sum() + ht.sum()).backward()
+    dt = time.time() - t0
+    threads = torch.get_num_threads()
+    return {"value": 1.0 / (30.0 * dt), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 30 DiT blocks, fwd+bwd, B=1, S=17776, fp32 eager PyTorch-CPU oracle, {dt:.1f} s measured, x30",
+            "block_seconds": dt, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--micro-batch", type=int, default=2)
+    ap.add_argument("--accum", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from vt355 import ops
+    from vt355.ddp import FlatGradReducer, broadcast_flat, init_from_env
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.lora import LoraConfig, get_peft_model
+    from vt355.optim import FusedAdamW
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.workflow import _LossFn
+
+    rank, local, world = init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- model: CogVideoX-2B architecture, seeded random init, identical on every rank ----
+    model = CogVideoXTransformer3DModel(num_layers=args.layers)
+    model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.normal_(0.0, 0.02, generator=gen)
+            if name.endswith(("norm.weight", "norm_final.weight", "norm_q.weight", "norm_k.weight")):
+                p.add_(1.0)
+    model.requires_grad_(False)
+    peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
+    st = peft._lora_state
+    broadcast_flat(st.flat); st.mark_changed()
+    lr = 6e-6 * world * args.micro_batch            # scripts/train.py:180-185  lr = world * bs * base_lr
+    opt = FusedAdamW(st.params, lr=lr, lora_state=st)
+    sched = CogVideoXDPMScheduler()
+    red = FlatGradReducer(st.grad)
+
+    B, Fr, C, Hh, Ww, St = args.micro_batch, 13, 16, 60, 90, 226
+    dgen = torch.Generator(device=dev).manual_seed(20230211 + rank)      # per-rank data / in-step RNG
+
+    def make_batch():
+        x0 = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
+        text = (torch.randn(B, St, 4096, device=dev, generator=dgen) * 0.2).to(torch.bfloat16)
+        noise = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
+        t = torch.randint(0, 1000, (B,), device=dev, generator=dgen)
+        return x0, text, noise, t
+
+    batches = [make_batch() for _ in range(args.accum)]
+    losses = []
+
+    def step():
+        nonlocal batches
+        opt.zero_grad()
+        for mb in range(args.accum):
+            x0, text, noise, t = batches[mb]
+            noisy = sched.add_noise(x0, noise, t)
+            out = peft(hidden_states=noisy, encoder_hidden_states=text, timestep=t, return_dict=False)[0]
+            sa, sb, w = sched.coefficients(t)
+            loss = _LossFn.apply(out, noisy, x0, sa, sb, w)
+            (loss / args.accum).backward()
+            losses.append(loss.detach())
+        red.reduce_async()                        # one RCCL all-reduce of the flat LoRA gradient ...
+        batches = [make_batch() for _ in range(args.accum)]   # ... overlapped with the next step's input generation
+        red.wait()
+        opt.step(grad_scale=red.grad_scale)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    ops.profile_reset(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    samples = world * args.micro_batch * args.accum * args.steps
+    loss_vals = [float(x) for x in torch.stack(losses[-args.accum * args.steps:]).cpu()]
+
+    if rank == 0:
+        S, d = St + Fr * (Hh // 2) * (Ww // 2), model.inner_dim
+        alg = {"attn_bwd": 8.0 * S * S * d * B, "attn_fwd": 4.0 * S * S * d * B}     # algorithmic FLOPs per launch
+        kern = {}
+        for name, (ms, n) in prof.items():
+            kern[name] = {"avg_ms": ms, "launches": n}
+            if name in alg:
+                kern[name]["tflops_algorithmic"] = alg[name] / ms / 1e9
+        dom = "attn_bwd"
+        ach = kern[dom]["tflops_algorithmic"] if dom in kern else None
+        res = {
+            "metric": "finetune samples/sec, CogVideoX-2B T2V LoRA 49x480x720 bf16", "value": samples / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CogVideoX-2B T2V LoRA finetune 49x480x720 (configs[1]): latents [2,13,16,60,90], "
+                                   "text [2,226,4096], r=4 LoRA on to_q/k/v/out, accumulate_grad_batches 2",
+                       "micro_batch": args.micro_batch, "accumulate_grad_batches": args.accum,
+                       "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": args.layers,
+                       "parallelism": f"dp{world}", "recompute": "none (activations kept in HBM)",
+                       "weights": "seeded random init (no checkpoints offline)"},
+            "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": None,
+                         "note": "algorithmic FLOPs per launch 8*S^2*d*B (dQ,dK,dV products; P recompute not counted)"},
+            "kernels": kern,
+            "loss_last": loss_vals[-1], "loss_first": loss_vals[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

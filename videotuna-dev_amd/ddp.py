@@ -1,0 +1,68 @@
+"""Data parallelism for the finetune path: one process per GPU, full replica each, disjoint sample shards, and ONE
+exchange step -- the gradient all-reduce -- exactly the reference's default ``DDPStrategy``
+(videotuna/utils/train_utils.py:127-139, scripts/train.py:215-217).  Because every trainable tensor lives in one
+flat fp32 buffer (vt355.lora.LoraState) the exchange is a single RCCL all-reduce (7.4 MB for CogVideoX-2B r=4),
+issued asynchronously so the next micro-batch's input preparation overlaps it; the 1/world average is folded into
+the fused AdamW's ``grad_scale`` (no extra pass over the gradients).  ``no_sync`` semantics: call ``reduce`` only on
+the last micro-batch of an accumulation window.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class FlatGradReducer:
+    """All-reduce (sum) of a flat gradient buffer; ``grad_scale`` = 1/world turns the sum into the DDP mean."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None):
+        self.grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._work = None
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def reduce_async(self):
+        if self.world > 1:
+            self._work = dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+    def reduce(self):
+        self.reduce_async()
+        self.wait()
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """DistributedSampler-style disjoint shard (no shuffling): item i goes to rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)

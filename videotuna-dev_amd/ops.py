@@ -20,6 +20,41 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-kernel timing with HIP events recorded on the stream the kernels are launched on ----
+_PROFILE = {"on": False, "events": {}}
+_PROFILED = ("attn_fwd", "attn_bwd")
+
+
+def profile_reset(on: bool):
+    _PROFILE["on"] = on
+    _PROFILE["events"] = {}
+
+
+def profile_collect():
+    """name -> (average ms per launch, launches); call after a stream synchronize."""
+    out = {}
+    for name, evs in _PROFILE["events"].items():
+        ts = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (sum(ts) / len(ts), len(ts))
+    return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROFILE["on"]:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _PROFILE["on"]:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream())
+            _PROFILE["events"].setdefault(self.name, []).append((self.a, b))
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -69,7 +104,8 @@ def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = 
         _req(t, BF16, n, 3)
     scale = 1.0 / math.sqrt(64) if scale is None else scale
     lib = load_library()
-    check(lib.vt_attn_fwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), B, H, S,
+    with _timed("attn_fwd"):
+      check(lib.vt_attn_fwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), B, H, S,
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1),
                                q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()),
           "vt_attn_fwd_hd64")
@@ -81,7 +117,8 @@ def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: 
         _req(t, BF16, n, 3)
     _req(dq_f32, torch.float32, "dq_f32", 3)
     lib = load_library()
-    check(lib.vt_attn_bwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
+    with _timed("attn_bwd"):
+      check(lib.vt_attn_bwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
                                lse2.data_ptr(), delta_ws.data_ptr(), dq_f32.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                B, H, S,
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1),

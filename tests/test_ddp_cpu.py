@@ -1,0 +1,47 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange (one all-reduce of the flat gradient, mean folded into the
+optimizer scale) and the sample sharding -- the N>1 path of bench.py without a GPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vt355.ddp import FlatGradReducer, broadcast_flat, init_from_env, shard_indices
+    r, _, w = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    flat = torch.full((1000,), float(rank + 1))
+    broadcast_flat(flat, src=0)
+    assert torch.all(flat == 1.0)                       # identical replicas after broadcast
+    grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    red = FlatGradReducer(grad)
+    red.reduce_async(); red.wait()
+    mean = grad * red.grad_scale
+    expect = torch.arange(1000, dtype=torch.float32) * (1 + 2) / 2
+    ok = torch.allclose(mean, expect) and red.world == 2
+    idx = shard_indices(10, rank, world)
+    out[rank] = (ok, idx)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_flat_allreduce_and_sharding_world2():
+    mgr = mp.Manager(); out = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][0] and out[1][0]
+    assert sorted(out[0][1] + out[1][1]) == list(range(10)) and not set(out[0][1]) & set(out[1][1])
+
+
+def test_single_process_reducer_is_identity():
+    from vt355.ddp import FlatGradReducer
+    g = torch.ones(8)
+    r = FlatGradReducer(g)
+    r.reduce()
+    assert r.grad_scale == 1.0 and torch.all(g == 1)

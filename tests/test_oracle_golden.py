@@ -1,0 +1,103 @@
+"""CPU: pin the oracle (oracle/cogvideox_oracle.py) to the golden vectors generated from the reference's own modules
+(tests/golden/make_golden.py).  fp32/fp64 restatements -> tight tolerances."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import cogvideox_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_timestep_sinusoid_matches_reference():
+    g = np.load(os.path.join(G, "timestep_embedding.npz"))
+    t = torch.from_numpy(g["t"])
+    assert np.abs(O.timestep_sinusoid(t, 1920).numpy() - g["emb1920"]).max() < 1e-6
+    assert np.abs(O.timestep_sinusoid(t, 64).numpy() - g["emb64"]).max() < 1e-6
+
+
+def test_pos_embed_matches_sat_twin():
+    g = np.load(os.path.join(G, "pos_embed_3d.npz"))
+    assert np.abs(O.sincos_pos_embed_3d(128, 6, 8, 3, 1.875, 1.0) - g["small"]).max() < 1e-12
+    full = O.sincos_pos_embed_3d(1920, 30, 45, 13, 1.875, 1.0).reshape(-1, 1920)
+    assert np.abs(full[g["full_rows_idx"]] - g["full_rows"]).max() < 1e-12
+    assert np.abs(full.sum(0) - g["full_colsum"]).max() < 1e-8 and np.abs(full.sum(1) - g["full_rowsum"]).max() < 1e-8
+    # the table the product builds is the same function (host-side numpy, not a kernel)
+    from vt355.dit import sincos_pos_embed_3d
+    assert np.abs(sincos_pos_embed_3d(128, 6, 8, 3, 1.875, 1.0).reshape(3, 48, 128) - g["small"]).max() < 1e-12
+
+
+def test_schedule_matches_zero_snr_discretizer():
+    g = np.load(os.path.join(G, "schedule_cogvideox.npz"))
+    for s in (1, 3):
+        ab = O.alphas_cumprod_cogvideox(snr_shift_scale=float(s))
+        assert np.abs(ab.sqrt().numpy() - g[f"sqrt_abar_shift{s}"]).max() < 2e-7      # reference rescales in fp32
+    assert O.alphas_cumprod_cogvideox()[-1].item() == 0.0
+    from vt355.scheduler import CogVideoXDPMScheduler
+    assert torch.equal(CogVideoXDPMScheduler().alphas_cumprod, O.alphas_cumprod_cogvideox())
+
+
+def test_qsample_getv_match_ddpm():
+    g = np.load(os.path.join(G, "ddpm_qsample_getv.npz"))
+    abar = torch.from_numpy(g["alphas_cumprod"]).float()
+    x0, nz, t = torch.from_numpy(g["x0"]), torch.from_numpy(g["noise"]), torch.from_numpy(g["t"])
+    assert (O.add_noise(x0, nz, t, abar) - torch.from_numpy(g["q_sample"])).abs().max() < 2e-6
+    assert (O.get_velocity(x0, nz, t, abar) - torch.from_numpy(g["get_v"])).abs().max() < 2e-6
+
+
+def test_modulate_and_unpatchify_conventions():
+    g = np.load(os.path.join(G, "modulate_unpatchify.npz"))
+    x, sh, sc = [torch.from_numpy(g[k]) for k in ("x", "shift", "scale")]
+    assert torch.equal(x * (1 + sc[:, None]) + sh[:, None], torch.from_numpy(g["modulated"]))
+    tok = torch.from_numpy(g["tokens"])
+    out = tok.reshape(2, 3, 2, 4, -1, 2, 2).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)   # oracle step 5
+    assert torch.equal(out, torch.from_numpy(g["unpatchified"]))
+
+
+def test_attention_with_qk_layernorm_matches_opensora_attention():
+    g = np.load(os.path.join(G, "opensora_primitives.npz"))
+    x = torch.from_numpy(g["attn_x"])
+    qkv = F.linear(x, torch.from_numpy(g["attn_qkv.weight"]), torch.from_numpy(g["attn_qkv.bias"]))
+    q, k, v = qkv.view(2, 24, 3, 2, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    q = F.layer_norm(q, (64,), torch.from_numpy(g["attn_q_norm.weight"]), torch.from_numpy(g["attn_q_norm.bias"]), 1e-5)
+    k = F.layer_norm(k, (64,), torch.from_numpy(g["attn_k_norm.weight"]), torch.from_numpy(g["attn_k_norm.bias"]), 1e-5)
+    o, _ = O.attention(q, k, v)
+    y = F.linear(o.transpose(1, 2).reshape(2, 24, 128), torch.from_numpy(g["attn_proj.weight"]), torch.from_numpy(g["attn_proj.bias"]))
+    assert (y - torch.from_numpy(g["attn_y"])).abs().max() < 1e-5
+    # modulate and GELU-tanh MLP primitives
+    xm = torch.from_numpy(g["mod_x"])
+    ym = F.layer_norm(xm, (128,), None, None, 1e-6) * (1 + torch.from_numpy(g["mod_scale"])) + torch.from_numpy(g["mod_shift"])
+    assert (ym - torch.from_numpy(g["mod_y"])).abs().max() < 1e-5
+    h = O.gelu_tanh(F.linear(xm, torch.from_numpy(g["mlp_fc1_w"]), torch.from_numpy(g["mlp_fc1_b"])))
+    assert (F.linear(h, torch.from_numpy(g["mlp_fc2_w"]), torch.from_numpy(g["mlp_fc2_b"])) - torch.from_numpy(g["mlp_y"])).abs().max() < 1e-5
+
+
+def test_attention_matches_lvdm_crossattention():
+    g = np.load(os.path.join(G, "lvdm_crossattention.npz"))
+    x = torch.from_numpy(g["x"])
+    q, k, v = [F.linear(x, torch.from_numpy(g[f"to_{n}_weight"])).view(2, 20, 2, 64).transpose(1, 2) for n in "qkv"]
+    o, _ = O.attention(q, k, v)
+    y = F.linear(o.transpose(1, 2).reshape(2, 20, 128), torch.from_numpy(g["to_out_0_weight"]), torch.from_numpy(g["to_out_0_bias"]))
+    assert (y - torch.from_numpy(g["y"])).abs().max() < 1e-5
+
+
+def test_oracle_train_step_runs_and_lora_zero_init_is_identity():
+    cfg = O.tiny_config()
+    P = O.init_params(cfg, 0)
+    B, Fr = 2, (cfg.sample_frames - 1) // 4 + 1
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(B, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g)
+    txt = torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g)
+    nz, t, abar = torch.randn(x0.shape, generator=g), torch.tensor([3, 900]), O.alphas_cumprod_cogvideox()
+    l0 = O.training_loss(P, cfg, x0, txt, nz, t, abar.float())
+    l1 = O.training_loss(P, cfg, x0, txt, nz, t, abar.float(), O.init_lora(cfg))        # B = 0 -> same loss
+    assert torch.isfinite(l0) and torch.allclose(l0, l1)
+    # AdamW restatement == torch.optim.AdamW
+    p = torch.randn(100, generator=g); gr = torch.randn(100, generator=g)
+    pt = p.clone().requires_grad_(True); opt = torch.optim.AdamW([pt], lr=1e-2)
+    m, v = torch.zeros(100), torch.zeros(100)
+    for i in range(3):
+        pt.grad = gr.clone(); opt.step(); O.adamw_step(p, gr, m, v, i + 1, 1e-2)
+    assert torch.allclose(p, pt.detach(), atol=1e-6)

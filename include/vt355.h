@@ -53,12 +53,14 @@ int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ld
 /* Flash attention forward, head_dim 64, non-causal.  Element (b,s,h,d) of q lives at
  * q + b*q_bs + s*q_rs + h*64 + d (same for k, v, o) so a fused QKV projection is consumed in place.
  * lse2[b,h,s] = log2(sum_j exp(scale * q.k_j)) (fp32), kept for the backward.
+ * q_prescaled != 0: q was already multiplied by softmax_scale*log2(e) (vt_qk_layernorm_fwd's q_scale), so the
+ * kernels use exp2 of the raw scores; dq is still the gradient wrt the UNscaled q_hat, dk wrt k_hat.
  * Replaces: F.scaled_dot_product_attention in diffusers CogVideoXAttnProcessor2_0 (cogvideo_pl.py:865-871). */
 int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float* lse2,
                      int B, int H, int S,
                      long long q_rs, long long k_rs, long long v_rs, long long o_rs,
                      long long q_bs, long long k_bs, long long v_bs, long long o_bs,
-                     float softmax_scale, void* stream);
+                     float softmax_scale, int q_prescaled, void* stream);
 
 /* Flash attention backward.  delta_ws: [B*H*S] fp32 workspace; dq_f32: fp32 [.., H*64] accumulation buffer
  * that the CALLER ZEROES beforehand (dQ is summed across key blocks with fp32 atomics); dk, dv bf16.
@@ -70,7 +72,7 @@ int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o,
                      long long dq_rs, long long dk_rs, long long dv_rs,
                      long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
                      long long dq_bs, long long dk_bs, long long dv_bs,
-                     float softmax_scale, void* stream);
+                     float softmax_scale, int q_prescaled, void* stream);
 
 /* y = LayerNorm(x; gamma, beta, eps) * (1 + scale[b,seg]) + shift[b,seg]; gamma/beta may be NULL (no
  * affine), the four modulation pointers may be NULL (plain LayerNorm).  mean/rstd [M] fp32 optional.
@@ -89,7 +91,7 @@ int vt_ln_modulate_bwd(const void* dy, int lddy, const void* x, int ldx, const f
  * [M, 2*H*64] (q_hat | k_hat) and the statistics [M, 2H].  Replaces attn.norm_q / attn.norm_k. */
 int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, const void* gq, const void* bq,
                         const void* gk, const void* bk, float* mean, float* rstd,
-                        long long M, int H, float eps, void* stream);
+                        long long M, int H, float eps, float q_scale, void* stream);
 int vt_qk_layernorm_bwd(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
                         const float* mean, const float* rstd, const void* gq, const void* gk,
                         void* dqkv, int ldd, long long M, int H, void* stream);

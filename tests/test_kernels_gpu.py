@@ -86,28 +86,46 @@ def _qkv(B, S, H, g, spike=False):
     return rb(qkv)
 
 
+SC2 = math.log2(math.e) / 8.0
+
+
+def _prescale(qkv, pre):
+    """device copy of qkv (q multiplied by scale*log2e and re-rounded when pre) + the exact q the kernel then sees."""
+    if not pre:
+        return qkv, qkv
+    dq = qkv.clone()
+    dq[:, :, 0] = rb(qkv[:, :, 0] * SC2)
+    ref = qkv.double().clone()
+    ref[:, :, 0] = dq[:, :, 0].double() / SC2
+    return dq, ref
+
+
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 1250, 2, False)])
-def test_attn_fwd(dev, B, S, H, spike):
+def test_attn_fwd(dev, B, S, H, spike, pre):
     from vt355 import ops
     g = torch.Generator().manual_seed(S)
     qkv = _qkv(B, S, H, g, spike)
-    q, k, v = [qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3)]
+    qkv_dev, qkv_ref = _prescale(qkv, pre)
+    q, k, v = [qkv_ref[:, :, i].permute(0, 2, 1, 3).double() for i in range(3)]
     o_ref, lse_ref = O.attention(q, k, v)
-    d = qkv.to(dev, BF).view(B, S, 3 * H * 64)
+    d = qkv_dev.to(dev, BF).view(B, S, 3 * H * 64)
     o = torch.empty(B, S, H * 64, dtype=BF, device=dev)
     lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-    ops.attn_fwd(d[:, :, :H * 64], d[:, :, H * 64:2 * H * 64], d[:, :, 2 * H * 64:], o, lse2, B, H, S)
+    ops.attn_fwd(d[:, :, :H * 64], d[:, :, H * 64:2 * H * 64], d[:, :, 2 * H * 64:], o, lse2, B, H, S, q_prescaled=pre)
     close(o.view(B, S, H, 64).permute(0, 2, 1, 3), o_ref, 2e-2, 1e-2, "attn out")
     close(lse2 * math.log(2.0), lse_ref, 1e-4, 2e-3, "lse")
 
 
-@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 700, 2, False)])
-def test_attn_bwd(dev, B, S, H, spike):
+@pytest.mark.parametrize("pre", [False, True])
+@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 700, 2, False), (1, 256, 1, False)])
+def test_attn_bwd(dev, B, S, H, spike, pre):
     from vt355 import ops
     g = torch.Generator().manual_seed(S + 1)
     qkv = _qkv(B, S, H, g, spike)
+    qkv, qkv_ref = _prescale(qkv, pre)
     do = rb(torch.randn(B, S, H, 64, generator=g))
-    qkv64 = qkv.double().requires_grad_(True)
+    qkv64 = qkv_ref.double().requires_grad_(True)
     q, k, v = [qkv64[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
     o_ref, _ = O.attention(q, k, v)
     o_ref.backward(do.permute(0, 2, 1, 3).double())
@@ -116,11 +134,11 @@ def test_attn_bwd(dev, B, S, H, spike):
     D = H * 64
     qd, kd, vd = d[:, :, :D], d[:, :, D:2 * D], d[:, :, 2 * D:]
     o = torch.empty(B, S, D, dtype=BF, device=dev); lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-    ops.attn_fwd(qd, kd, vd, o, lse2, B, H, S)
+    ops.attn_fwd(qd, kd, vd, o, lse2, B, H, S, q_prescaled=pre)
     dq = torch.zeros(B, S, D, dtype=torch.float32, device=dev)
     dk = torch.empty(B, S, D, dtype=BF, device=dev); dv = torch.empty(B, S, D, dtype=BF, device=dev)
     delta = torch.empty(B * H * S, dtype=torch.float32, device=dev)
-    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(B, S, D), lse2, delta, dq, dk, dv, B, H, S)
+    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(B, S, D), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=pre)
     scale = dref.abs().max().item()
     close(dq.view(B, S, H, 64), dref[:, :, 0], 3e-2, 1e-2 * scale, "dq")
     close(dk.view(B, S, H, 64), dref[:, :, 1], 3e-2, 1e-2 * scale, "dk")
@@ -183,6 +201,8 @@ def test_qk_layernorm(dev):
     dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
     ops.qk_layernorm_bwd(dqh.to(dev), dkh.to(dev, BF), Q, mean, rstd, dv[0], dv[2], dqkv, H)
     close(dqkv[:, :2 * D], x.grad[:, :2 * D], 2e-2, 2e-2, "qk-LN bwd")
+    ops.qk_layernorm_fwd(Q, out, dv[0], dv[1], dv[2], dv[3], mean, rstd, H, 1e-6, q_scale=SC2)
+    close(out[:, :D], qh * SC2, 1e-2, 5e-3, "q_hat prescaled"); close(out[:, D:], kh, 1e-2, 2e-2, "k_hat untouched")
 
 
 # ------------------------------------------------------------------ elementwise

@@ -45,14 +45,14 @@ def main():
         qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)
         q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
         o = torch.empty(B, S, d, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
-        med, mn = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, B, H, S), iters=5, warm=2)
+        med, mn = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, B, H, S, q_prescaled=True), iters=5, warm=2)
         fl = 4.0 * S * S * d * B
         res["attn_fwd"] = dict(ms=med, tflops=fl / med / 1e9)
         print(f"attn fwd: {med:.3f} ms  {fl/med/1e9:.0f} TF/s (min {mn:.3f})", flush=True)
         do = torch.randn(B, S, d, device=dev).to(BF)
         dq = torch.zeros(B, S, d, device=dev); dk = torch.empty(B, S, d, dtype=BF, device=dev); dv = torch.empty_like(dk)
         delta = torch.empty(B * H * S, device=dev)
-        med, mn = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S), iters=5, warm=2)
+        med, mn = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S, q_prescaled=True), iters=5, warm=2)
         fl2 = 2.5 * fl
         res["attn_bwd"] = dict(ms=med, tflops_exec=fl2 / med / 1e9, tflops_alg=2 * fl / med / 1e9)
         print(f"attn bwd: {med:.3f} ms  {fl2/med/1e9:.0f} TF/s executed (5 products), {2*fl/med/1e9:.0f} algorithmic (min {mn:.3f})", flush=True)

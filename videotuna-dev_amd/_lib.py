@@ -25,12 +25,12 @@ PROTOTYPES = {
     "vt_error_string": [_i],
     "vt_gemm_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _fp, _fp, _i, _i, _i,
                      _vp, _i, _vp, _i, _vp],
-    "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+    "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
-                         _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+                         _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
     "vt_ln_modulate_fwd": [_vp, _i, _vp, _i, _vp, _vp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "vt_ln_modulate_bwd": [_vp, _i, _vp, _i, _fp, _fp, _vp, _fp, _fp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _vp],
+    "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _f, _vp],
     "vt_qk_layernorm_bwd": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _vp, _vp, _vp, _i, _ll, _i, _vp],
     "vt_gate_mul": [_vp, _i, _vp, _i, _fp, _fp, _i, _ll, _i, _i, _i, _vp],
     "vt_silu_bf16": [_vp, _vp, _ll, _vp],

@@ -31,6 +31,7 @@ struct AttnFwdParams {
 #define FK 64       // keys per tile
 #define NEG_BIG (-1.0e30f)
 
+template <bool PRESCALED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[32768];   // 2 x (K 8 KiB + V 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * sc);
+        const float m_new = fmaxf(m_run, PRESCALED ? mx : mx * sc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float pv = __builtin_amdgcn_exp2f(st[kt2][i] * sc - m_new);
+                float pv = __builtin_amdgcn_exp2f(PRESCALED ? st[kt2][i] - m_new : st[kt2][i] * sc - m_new);
                 st[kt2][i] = pv;
                 psum += pv;
             }
@@ -212,7 +213,7 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
                                 int B, int H, int S,
                                 long long q_rs, long long k_rs, long long v_rs, long long o_rs,
                                 long long q_bs, long long k_bs, long long v_bs, long long o_bs,
-                                float softmax_scale, void* stream) {
+                                float softmax_scale, int q_prescaled, void* stream) {
     if (B <= 0 || H <= 0 || S <= 0) return VT_ERR_BAD_SHAPE;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4))
         return VT_ERR_BAD_SHAPE;
@@ -226,6 +227,7 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const int nqt = (S + FQ - 1) / FQ;
-    hipLaunchKernelGGL(attn_fwd_hd64_kernel, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
+    if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -220,7 +220,7 @@ extern "C" int vt_ln_modulate_bwd(const void* dy, int lddy, const void* x, int l
 __global__ __launch_bounds__(256) void qk_layernorm_fwd_kernel(const bf16_t* qkv, int ld, bf16_t* out, int ldo,
                                                               const bf16_t* gq, const bf16_t* bq, const bf16_t* gk,
                                                               const bf16_t* bk, float* mean, float* rstd,
-                                                              long long M, int H, float eps) {
+                                                              long long M, int H, float eps, float q_scale) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long grp = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -249,9 +249,10 @@ __global__ __launch_bounds__(256) void qk_layernorm_fwd_kernel(const bf16_t* qkv
     float ga[8], be[8];
     unpack8(*(const u32x4*)((isk ? gk : gq) + sub * 8), ga);
     unpack8(*(const u32x4*)((isk ? bk : bq) + sub * 8), be);
+    const float osc = isk ? 1.0f : q_scale;     // q_hat may be pre-multiplied by softmax_scale*log2(e) for the attention kernels
     float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rs * ga[j] + be[j];
+    for (int j = 0; j < 8; ++j) o[j] = ((v[j] - mu) * rs * ga[j] + be[j]) * osc;
     *(u32x4*)(out + (size_t)m * ldo + wh * 64 + sub * 8) = pack8(o);
     if (sub == 0) { mean[m * 2 * H + wh] = mu; rstd[m * 2 * H + wh] = rs; }
 }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void qk_layernorm_bwd_kernel(const float* dqh,
 
 extern "C" int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, const void* gq, const void* bq,
                                    const void* gk, const void* bk, float* mean, float* rstd,
-                                   long long M, int H, float eps, void* stream) {
+                                   long long M, int H, float eps, float q_scale, void* stream) {
     if (M <= 0 || H <= 0 || (ld % 8) || (ldo % 8) || ld < 2 * H * 64 || ldo < 2 * H * 64) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)gq) | ((uintptr_t)bq) | ((uintptr_t)gk) | ((uintptr_t)bk)) & 15)
         return VT_ERR_BAD_ALIGN;
@@ -315,7 +316,7 @@ extern "C" int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, 
     if (blocks > 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(qk_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, ld, (bf16_t*)out, ldo, (const bf16_t*)gq, (const bf16_t*)bq,
-                       (const bf16_t*)gk, (const bf16_t*)bk, mean, rstd, M, H, eps);
+                       (const bf16_t*)gk, (const bf16_t*)bk, mean, rstd, M, H, eps, q_scale);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

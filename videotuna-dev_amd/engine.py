@@ -17,6 +17,8 @@ from . import ops
 from .ops import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_GATED_RES
 
 EXT = 64
+# q_hat is stored pre-multiplied by softmax_scale * log2(e) (head_dim 64) so the attention kernels exponentiate raw scores
+Q_PRESCALE = 1.4426950408889634 / 8.0
 
 
 def _lin(mod):
@@ -157,11 +159,11 @@ def run_forward(model, x, text, t, save: bool):
         ops.gemm(x1, Lw.w_qkv, qkv, Lw.b_qkv, K=KE)
         qkh = E(M, 2 * d)
         a.qmean, a.qrstd = E(M, 2 * H, dt=torch.float32), E(M, 2 * H, dt=torch.float32)
-        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6)
+        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6, q_scale=Q_PRESCALE)
         o = E(M, d + EXT)
         lse = E(B, H, S, dt=torch.float32)
         qk3, qkv3, o3 = qkh.view(B, S, 2 * d), qkv.view(B, S, 3 * d), o.view(B, S, d + EXT)
-        ops.attn_fwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], o3[:, :, :d], lse, B, H, S)
+        ops.attn_fwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], o3[:, :, :d], lse, B, H, S, q_prescaled=True)
         if st is not None:
             ops.lora_down(o, st.a_out(st.flat_bf16, i), st.r, o[:, d:], d)
         h1 = E(M, d)
@@ -258,7 +260,7 @@ def run_backward(model, ctx, dout: torch.Tensor):
         qk3, qkv3 = a.qkh.view(B, S, 2 * d), a.qkv.view(B, S, 3 * d)
         ops.attn_bwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], a.o.view(B, S, d + EXT)[:, :, :d],
                      dO.view(B, S, d + EXT)[:, :, :d], a.lse, delta, dq, dkh.view(B, S, d),
-                     dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S)
+                     dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S, q_prescaled=True)
         ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H)
         ops.gemm(dqkv, Lw.w_qkv_t, dx1, None)                             # [M, d+EXT]: dx1 | dT1
         for j in range(3):

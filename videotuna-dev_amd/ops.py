@@ -98,7 +98,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     return out
 
 
-def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None):
+def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None, q_prescaled: bool = False):
     """q,k,v,o: views whose element (b,s,h,d) is at base + b*bs + s*rs + h*64 + d; given as 3-d [B,S,>=H*64]."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         _req(t, BF16, n, 3)
@@ -107,11 +107,12 @@ def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = 
     with _timed("attn_fwd"):
       check(lib.vt_attn_fwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), B, H, S,
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1),
-                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()),
+                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, int(q_prescaled), _stream()),
           "vt_attn_fwd_hd64")
 
 
-def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: int, scale: Optional[float] = None):
+def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: int, scale: Optional[float] = None,
+             q_prescaled: bool = False):
     scale = 1.0 / math.sqrt(64) if scale is None else scale
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dk", dk), ("dv", dv)):
         _req(t, BF16, n, 3)
@@ -124,7 +125,7 @@ def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: 
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1),
                                dq_f32.stride(1), dk.stride(1), dv.stride(1),
                                q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
-                               dq_f32.stride(0), dk.stride(0), dv.stride(0), scale, _stream()),
+                               dq_f32.stride(0), dk.stride(0), dv.stride(0), scale, int(q_prescaled), _stream()),
           "vt_attn_bwd_hd64")
 
 
@@ -148,12 +149,12 @@ def ln_modulate_bwd(dy, x, mean, rstd, gamma, scales, dres, dx, D: int, S: int, 
                                  dx.data_ptr(), dx.stride(0), x.shape[0], D, S, St, _stream()), "vt_ln_modulate_bwd")
 
 
-def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float):
+def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float, q_scale: float = 1.0):
     _req(qkv, BF16, "qkv", 2); _req(out, BF16, "out", 2)
     lib = load_library()
     check(lib.vt_qk_layernorm_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), bq.data_ptr(),
                                   gk.data_ptr(), bk.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.shape[0], H, eps,
-                                  _stream()), "vt_qk_layernorm_fwd")
+                                  q_scale, _stream()), "vt_qk_layernorm_fwd")
 
 
 def qk_layernorm_bwd(dq_hat_f32, dk_hat, qkv, mean, rstd, gq, gk, dqkv, H: int):

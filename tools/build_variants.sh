@@ -6,8 +6,8 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../videotuna-dev_amd/csrc" && pwd)"
 OUT="$HERE/../libvt355_exp.so"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics"
 mkdir -p "$HERE/obj_exp"; rm -f "$HERE"/obj_exp/*.o
-for a in 1 2 3 4; do hipcc $F -DVT_SUFFIX=_abl$a -DVT_ABL=$a -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl$a.o" & done
-hipcc $F -DVT_SUFFIX=_np -DVT_PIPE=0 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_np.o" &
+for n in 2 3; do hipcc $F -DVT_SUFFIX=_n$n -DVT_NKB=$n -c "$HERE/exp/attn_bwd_nkb.hip" -o "$HERE/obj_exp/bwd_n$n.o" & done
+for a in 1 2; do hipcc $F -DVT_SUFFIX=_abl$a -DVT_ABL=$a -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl$a.o" & done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj_exp/*.o
 echo "built $OUT"

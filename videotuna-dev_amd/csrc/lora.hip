@@ -53,8 +53,10 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
 }
 
 // ---------------- out[p*osp + r*osr] += alpha * sum_m Big[m,p] * Small[m,r]   (fp32 atomics) ----------------
-// Thread = 4 consecutive columns p, RR accumulators each; block = 1024 columns x 128 rows of m.
-#define SK_ROWS 128
+// Thread = 4 consecutive columns p (one 8-byte load per row), RR accumulators each; block = 1024 columns x SK_ROWS rows.
+// Rows are walked 8 at a time with all 8 loads issued before the first use, and the grid has >= 4 blocks per CU, so the
+// kernel streams Big at HBM rate instead of waiting on one load at a time.
+#define SK_ROWS 64
 template <int RR>
 __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
                                                        float* out, long long osp, long long osr, float alpha,
@@ -62,7 +64,6 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int l
     __shared__ __attribute__((aligned(16))) float sm[SK_ROWS * RR];
     const long long m0 = (long long)blockIdx.y * SK_ROWS;
     const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
-    // stage Small[m0 .. m0+127][0..RR) as fp32 (zero past M or past R)
     for (int i = threadIdx.x; i < SK_ROWS * RR; i += 256) {
         const int mm = i / RR, rr = i - mm * RR;
         const long long m = m0 + mm;
@@ -77,20 +78,28 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int l
         for (int rr = 0; rr < RR; ++rr) acc[c][rr] = 0.f;
     const int rows = (int)((M - m0) < SK_ROWS ? (M - m0) : SK_ROWS);
     const bf16_t* bp = Big + (size_t)m0 * ldb + p;
-#pragma unroll 4
-    for (int mm = 0; mm < rows; ++mm) {
-        u32x2 raw = *(const u32x2*)(bp + (size_t)mm * ldb);
-        const float b0 = __uint_as_float(raw[0] << 16), b1 = __uint_as_float(raw[0] & 0xffff0000u);
-        const float b2 = __uint_as_float(raw[1] << 16), b3 = __uint_as_float(raw[1] & 0xffff0000u);
+    for (int mb = 0; mb < SK_ROWS; mb += 8) {
+        u32x2 raw[8];
 #pragma unroll
-        for (int r4 = 0; r4 < RR / 4; ++r4) {
-            f32x4 s = *(const f32x4*)(sm + mm * RR + 4 * r4);
+        for (int u = 0; u < 8; ++u) {
+            const int mm = mb + u;
+            raw[u] = *(const u32x2*)(bp + (size_t)(mm < rows ? mm : rows - 1) * ldb);   // clamp: Small is zero past the end
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][4 * r4 + j] += b0 * s[j];
-                acc[1][4 * r4 + j] += b1 * s[j];
-                acc[2][4 * r4 + j] += b2 * s[j];
-                acc[3][4 * r4 + j] += b3 * s[j];
+        for (int u = 0; u < 8; ++u) {
+            const int mm = mb + u;
+            const float b0 = __uint_as_float(raw[u][0] << 16), b1 = __uint_as_float(raw[u][0] & 0xffff0000u);
+            const float b2 = __uint_as_float(raw[u][1] << 16), b3 = __uint_as_float(raw[u][1] & 0xffff0000u);
+#pragma unroll
+            for (int r4 = 0; r4 < RR / 4; ++r4) {
+                f32x4 s = *(const f32x4*)(sm + mm * RR + 4 * r4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][4 * r4 + j] += b0 * s[j];
+                    acc[1][4 * r4 + j] += b1 * s[j];
+                    acc[2][4 * r4 + j] += b2 * s[j];
+                    acc[3][4 * r4 + j] += b3 * s[j];
+                }
             }
         }
     }

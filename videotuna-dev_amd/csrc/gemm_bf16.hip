@@ -14,6 +14,18 @@
 // residual / writes C in row-contiguous, fully coalesced 128-B segments.
 #include "common.h"
 
+// variant hooks (tools/build_variants.sh); the shipped build defines none of these
+#ifndef VT_SUFFIX
+#define VT_SUFFIX
+#endif
+#ifndef VT_GEMM_DMA
+#define VT_GEMM_DMA 1      // 1 = operands staged by LDS-DMA (buffer_load ... lds), 0 = global -> VGPR -> ds_write_b128
+#endif
+#define VT_CAT_(a, b) a##b
+#define VT_CAT(a, b) VT_CAT_(a, b)
+#define GEMM_KERNEL VT_CAT(gemm_tn_kernel, VT_SUFFIX)
+#define GEMM_ENTRY VT_CAT(vt_gemm_bf16, VT_SUFFIX)
+
 struct GemmParams {
     const bf16_t* A;
     const bf16_t* W;
@@ -38,7 +50,7 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_DGELU = 3 };
 #define CS_LD 132   // fp32 row stride of the epilogue staging tile (64 rows x 132 floats = 33 KiB)
 
 template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void GEMM_KERNEL(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[65536];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -60,6 +72,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (size_t)row0 * p.lda, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
     __amdgpu_buffer_rsrc_t rw = make_rsrc(p.W + (size_t)col0 * p.ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
 
+#if VT_GEMM_DMA
+    // ---- LDS-DMA staging: a K-tile of A (and of W) is 16 blocks of 1 KiB = 8 rows x 128 B; wave w moves blocks
+    // w, w+4, w+8, w+12 of each operand.  One buffer_load..lds writes lane l at block + 16 l = (row l>>3, physical
+    // chunk l&7), so the XOR swizzle is applied to the SOURCE chunk; out-of-range rows read zeros (bounds check).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int drl = lane >> 3, dcp = lane & 7;
+    int a_voff[4], w_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drl;
+        a_voff[j] = row * p.lda * 2 + ((dcp ^ drl) << 4);
+        w_voff[j] = row * p.ldw * 2 + ((dcp ^ drl) << 4);
+    }
+    auto dma = [&](int kt, int buf) {
+        const int soff = kt * BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* dst = smem + buf * 32768 + (wv + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, a_voff[j], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 16384), 16, w_voff[j], soff, 0, 0);
+        }
+    };
+#else
     // staging assignment: 4 x 16-byte chunks of A and of W per thread per K-tile
     int a_voff[4], w_voff[4], lds_off[4];
 #pragma unroll
@@ -87,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
             *(u32x4*)(base + 16384 + lds_off[j]) = gw[j];
         }
     };
+#endif
 
     f32x4 acc[4][4];   // [tn][tm]
 #pragma unroll
@@ -95,15 +131,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
+#if VT_GEMM_DMA
+    dma(0, 0);
+#else
     gload(0);
     lstore(0);
+#endif
     __syncthreads();
     const int frow = lane & 15;            // row inside a 16-row fragment
     const int fq = lane >> 4;              // k-chunk inside a 32-deep k-step
     const int fx = lane & 7;               // == (row & 7) for every fragment row this lane reads
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#if VT_GEMM_DMA
+        if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+#else
         if (kt + 1 < nk) gload(kt + 1);
+#endif
         const char* As = smem + buf * 32768;
         const char* Ws = As + 16384;
 #pragma unroll
@@ -121,8 +165,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
         }
+#if !VT_GEMM_DMA
         if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+#endif
+        __syncthreads();       // (DMA build: the barrier's vmcnt(0) also retires the next tile's LDS-DMA)
     }
 
     // ---------------- epilogue: two 64-row halves through LDS ----------------
@@ -202,22 +248,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p) {
 }
 
 template <int EPI, bool F32>
-static int launch(const GemmParams& p, hipStream_t st) {
+static int VT_CAT(launch, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tn_kernel<EPI, F32>), dim3(nbm * nbn), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((GEMM_KERNEL<EPI, F32>), dim3(nbm * nbn), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 
-static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static bool VT_CAT(al16, VT_SUFFIX)(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-extern "C" int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                             int M, int N, int K, const void* bias, int epilogue, int out_fp32,
                             const void* R, int ldr, int r_mod,
                             const float* gate_txt, const float* gate_vid, int gate_bstride, int S, int St,
                             void* C2, int ldc2, const void* U, int ldu, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return VT_ERR_BAD_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldc % 4) || lda < K || ldw < K || ldc < N) return VT_ERR_BAD_SHAPE;
-    if (!al16(A) || !al16(W) || !al16(C)) return VT_ERR_BAD_ALIGN;
+    if (!VT_CAT(al16, VT_SUFFIX)(A) || !VT_CAT(al16, VT_SUFFIX)(W) || !VT_CAT(al16, VT_SUFFIX)(C)) return VT_ERR_BAD_ALIGN;
     GemmParams p;
     p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = (const bf16_t*)bias;
     p.R = (const bf16_t*)R; p.gate_txt = gate_txt; p.gate_vid = gate_vid;
@@ -227,18 +273,18 @@ extern "C" int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case EPI_BIAS:
-            return out_fp32 ? launch<EPI_BIAS, true>(p, st) : launch<EPI_BIAS, false>(p, st);
+            return out_fp32 ? VT_CAT(launch, VT_SUFFIX)<EPI_BIAS, true>(p, st) : VT_CAT(launch, VT_SUFFIX)<EPI_BIAS, false>(p, st);
         case EPI_BIAS_GELU:
-            if (out_fp32 || C2 == nullptr || (ldc2 % 4) || !al16(C2)) return VT_ERR_BAD_SHAPE;
-            return launch<EPI_BIAS_GELU, false>(p, st);
+            if (out_fp32 || C2 == nullptr || (ldc2 % 4) || !VT_CAT(al16, VT_SUFFIX)(C2)) return VT_ERR_BAD_SHAPE;
+            return VT_CAT(launch, VT_SUFFIX)<EPI_BIAS_GELU, false>(p, st);
         case EPI_GATED_RES:
-            if (out_fp32 || R == nullptr || (ldr % 4) || !al16(R)) return VT_ERR_BAD_SHAPE;
-            if (gate_vid != nullptr && (gate_txt == nullptr || (gate_bstride % 4) || !al16(gate_vid) || !al16(gate_txt)))
+            if (out_fp32 || R == nullptr || (ldr % 4) || !VT_CAT(al16, VT_SUFFIX)(R)) return VT_ERR_BAD_SHAPE;
+            if (gate_vid != nullptr && (gate_txt == nullptr || (gate_bstride % 4) || !VT_CAT(al16, VT_SUFFIX)(gate_vid) || !VT_CAT(al16, VT_SUFFIX)(gate_txt)))
                 return VT_ERR_BAD_SHAPE;
-            return launch<EPI_GATED_RES, false>(p, st);
+            return VT_CAT(launch, VT_SUFFIX)<EPI_GATED_RES, false>(p, st);
         case EPI_DGELU:
-            if (out_fp32 || U == nullptr || (ldu % 4) || !al16(U)) return VT_ERR_BAD_SHAPE;
-            return launch<EPI_DGELU, false>(p, st);
+            if (out_fp32 || U == nullptr || (ldu % 4) || !VT_CAT(al16, VT_SUFFIX)(U)) return VT_ERR_BAD_SHAPE;
+            return VT_CAT(launch, VT_SUFFIX)<EPI_DGELU, false>(p, st);
         default:
             return VT_ERR_UNSUPPORTED;
     }

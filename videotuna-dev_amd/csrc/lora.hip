@@ -53,21 +53,24 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
 }
 
 // ---------------- out[p*osp + r*osr] += alpha * sum_m Big[m,p] * Small[m,r]   (fp32 atomics) ----------------
-// Thread = 4 consecutive columns p (one 8-byte load per row), RR accumulators each; block = 1024 columns x SK_ROWS rows.
-// Rows are walked 8 at a time with all 8 loads issued before the first use, and the grid has >= 4 blocks per CU, so the
-// kernel streams Big at HBM rate instead of waiting on one load at a time.
-#define SK_ROWS 64
+// The output is tiny (P x R) and every block adds into all of it, so the cost is the CONTENDED atomics, not the
+// streaming: M is cut into only SK_SLICES row slices (one atomic per output element per slice), columns into 512-wide
+// blocks of 128 threads (4 columns = one 8-byte load per thread and row), and the rows of a slice are walked 16 at a
+// time with all 16 loads in flight.  The slice's Small rows are staged once in LDS as fp32.
+#define SK_SLICES 128
+#define SK_MAXROWS 256         // rows per slice that fit the LDS staging (32768 rows per launch chunk)
 template <int RR>
-__global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
+__global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
                                                        float* out, long long osp, long long osr, float alpha,
-                                                       long long M, int P) {
-    __shared__ __attribute__((aligned(16))) float sm[SK_ROWS * RR];
-    const long long m0 = (long long)blockIdx.y * SK_ROWS;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
-    for (int i = threadIdx.x; i < SK_ROWS * RR; i += 256) {
+                                                       long long M, int P, int rows_per_slice) {
+    __shared__ __attribute__((aligned(16))) float sm[SK_MAXROWS * RR];
+    const long long m0 = (long long)blockIdx.y * rows_per_slice;
+    if (m0 >= M) return;
+    const int rows = (int)((M - m0) < rows_per_slice ? (M - m0) : rows_per_slice);
+    const int p = (blockIdx.x * 128 + threadIdx.x) * 4;
+    for (int i = threadIdx.x; i < rows * RR; i += 128) {
         const int mm = i / RR, rr = i - mm * RR;
-        const long long m = m0 + mm;
-        sm[i] = (m < M && rr < R) ? bf2f(Small[(size_t)m * lds_ + rr]) : 0.f;
+        sm[i] = rr < R ? bf2f(Small[(size_t)(m0 + mm) * lds_ + rr]) : 0.f;
     }
     __syncthreads();
     if (p >= P) return;
@@ -76,23 +79,19 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int l
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) acc[c][rr] = 0.f;
-    const int rows = (int)((M - m0) < SK_ROWS ? (M - m0) : SK_ROWS);
     const bf16_t* bp = Big + (size_t)m0 * ldb + p;
-    for (int mb = 0; mb < SK_ROWS; mb += 8) {
-        u32x2 raw[8];
+    int mb = 0;
+    for (; mb + 16 <= rows; mb += 16) {
+        u32x2 raw[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int mm = mb + u;
-            raw[u] = *(const u32x2*)(bp + (size_t)(mm < rows ? mm : rows - 1) * ldb);   // clamp: Small is zero past the end
-        }
+        for (int u = 0; u < 16; ++u) raw[u] = *(const u32x2*)(bp + (size_t)(mb + u) * ldb);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int mm = mb + u;
+        for (int u = 0; u < 16; ++u) {
             const float b0 = __uint_as_float(raw[u][0] << 16), b1 = __uint_as_float(raw[u][0] & 0xffff0000u);
             const float b2 = __uint_as_float(raw[u][1] << 16), b3 = __uint_as_float(raw[u][1] & 0xffff0000u);
 #pragma unroll
             for (int r4 = 0; r4 < RR / 4; ++r4) {
-                f32x4 s = *(const f32x4*)(sm + mm * RR + 4 * r4);
+                f32x4 s = *(const f32x4*)(sm + (mb + u) * RR + 4 * r4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[0][4 * r4 + j] += b0 * s[j];
@@ -101,6 +100,16 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const bf16_t* Big, int l
                     acc[3][4 * r4 + j] += b3 * s[j];
                 }
             }
+        }
+    }
+    for (; mb < rows; ++mb) {
+        u32x2 raw = *(const u32x2*)(bp + (size_t)mb * ldb);
+        const float b0 = __uint_as_float(raw[0] << 16), b1 = __uint_as_float(raw[0] & 0xffff0000u);
+        const float b2 = __uint_as_float(raw[1] << 16), b3 = __uint_as_float(raw[1] & 0xffff0000u);
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+            const float sv = sm[mb * RR + rr];
+            acc[0][rr] += b0 * sv; acc[1][rr] += b1 * sv; acc[2][rr] += b2 * sv; acc[3][rr] += b3 * sv;
         }
     }
 #pragma unroll
@@ -113,14 +122,19 @@ extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds
                             long long osr, float alpha, long long M, int P, void* stream) {
     if (M <= 0 || P <= 0 || (P % 4) || R <= 0 || R > 16 || (ldb % 4)) return VT_ERR_BAD_SHAPE;
     if (((uintptr_t)Big) & 7) return VT_ERR_BAD_ALIGN;
-    dim3 grid((P + 1023) / 1024, (unsigned)((M + SK_ROWS - 1) / SK_ROWS));
     hipStream_t st = (hipStream_t)stream;
-    if (R <= 4)
-        hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)Big, ldb, (const bf16_t*)Small, lds_, R, out,
-                           osp, osr, alpha, M, P);
-    else
-        hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(256), 0, st, (const bf16_t*)Big, ldb, (const bf16_t*)Small, lds_, R, out,
-                           osp, osr, alpha, M, P);
+    const long long chunk = (long long)SK_SLICES * SK_MAXROWS;          // rows handled per launch
+    for (long long mbase = 0; mbase < M; mbase += chunk) {
+        const long long mc = (M - mbase) < chunk ? (M - mbase) : chunk;
+        const int rps = (int)((mc + SK_SLICES - 1) / SK_SLICES);
+        dim3 grid((P + 511) / 512, SK_SLICES);
+        const bf16_t* bg = (const bf16_t*)Big + (size_t)mbase * ldb;
+        const bf16_t* smp = (const bf16_t*)Small + (size_t)mbase * lds_;
+        if (R <= 4)
+            hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps);
+        else
+            hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps);
+    }
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -45,8 +45,10 @@ def main():
         qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)
         q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
         o = torch.empty(B, S, d, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+        med0, _ = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, B, H, S, q_prescaled=False), iters=5, warm=2)
         med, mn = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, B, H, S, q_prescaled=True), iters=5, warm=2)
         fl = 4.0 * S * S * d * B
+        print(f"attn fwd (classic online softmax, unscaled q): {med0:.3f} ms  {fl/med0/1e9:.0f} TF/s", flush=True)
         res["attn_fwd"] = dict(ms=med, tflops=fl / med / 1e9)
         print(f"attn fwd: {med:.3f} ms  {fl/med/1e9:.0f} TF/s (min {mn:.3f})", flush=True)
         do = torch.randn(B, S, d, device=dev).to(BF)

@@ -30,6 +30,7 @@ struct AttnFwdParams {
 #define FQ 128      // queries per workgroup
 #define FK 64       // keys per tile
 #define NEG_BIG (-1.0e30f)
+#define LAZY_THR 8.0f
 
 template <bool PRESCALED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) {
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
     f32x16 o_acc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o_acc[0][i] = 0.f; o_acc[1][i] = 0.f; }
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_run = PRESCALED ? 0.f : NEG_BIG, l_run = 0.f;
+    f32x16 negm;                                  // PRESCALED: -m_run broadcast, the initial S^T accumulator
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     const float sc = p.scale_log2;
 
     const int nt = (p.S + FK - 1) / FK;
@@ -122,8 +126,58 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         if (t + 1 < nt) gload(t + 1);
         const char* base = smem + buf * 16384;
 
-        // ---- S^T = K Q^T : 2 key sub-tiles x 4 k-steps ----
         f32x16 st[2];
+        if constexpr (PRESCALED) {
+            // ---- lazy-max online softmax (q carries softmax_scale*log2e): the accumulators START at -m_ref, so the
+            // MFMA chain delivers s - m_ref and P = exp2(st) needs no subtraction; O and l are rescaled only when some
+            // row's maximum grew by more than LAZY_THR (P then stays <= 2^LAZY_THR), which is rare after the first tiles.
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2) {
+                    bf16x8 kf = *(const bf16x8*)(base + kt2 * 4096 + kfo[s]);
+                    st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? negm : st[kt2], 0, 0, 0);
+                }
+            }
+            if ((t + 1) * FK > p.S) {
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        int key = t * FK + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= p.S) st[kt2][i] = NEG_BIG;
+                    }
+            }
+            float mx = st[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (t == 0 || !__all(mx <= LAZY_THR)) {            // wave-uniform
+                const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+                const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    o_acc[0][i] *= alpha; o_acc[1][i] *= alpha;
+                    st[0][i] -= delta; st[1][i] -= delta;
+                    negm[i] = -m_run;
+                }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float pv = __builtin_amdgcn_exp2f(st[kt2][i]);
+                    st[kt2][i] = pv;
+                    psum += pv;
+                }
+            l_run += psum;
+        } else {
+        // ---- S^T = K Q^T : 2 key sub-tiles x 4 k-steps ----
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
 #pragma unroll
@@ -166,6 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o_acc[0][i] *= alpha; o_acc[1][i] *= alpha; }
+
+        }
 
         // ---- O^T += V^T P^T : 2 d-tiles x (2 key sub-tiles x 2 k-steps) ----
 #pragma unroll

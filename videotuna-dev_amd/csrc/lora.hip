@@ -57,8 +57,8 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
 // streaming: M is cut into only SK_SLICES row slices (one atomic per output element per slice), columns into 512-wide
 // blocks of 128 threads (4 columns = one 8-byte load per thread and row), and the rows of a slice are walked 16 at a
 // time with all 16 loads in flight.  The slice's Small rows are staged once in LDS as fp32.
-#define SK_SLICES 128
-#define SK_MAXROWS 256         // rows per slice that fit the LDS staging (32768 rows per launch chunk)
+#define SK_SLICES 64
+#define SK_MAXROWS 512         // rows per slice that fit the LDS staging (32768 rows per launch chunk)
 template <int RR>
 __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
                                                        float* out, long long osp, long long osr, float alpha,

@@ -65,8 +65,11 @@ def main():
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.workflow import _LossFn
 
-    rank, local, world = init_from_env()
+    # VT_DDP_BACKEND=gloo + VT_ONE_GPU=1 rehearse the multi-rank control flow on a single-GPU box (tests only)
+    rank, local, world = init_from_env(os.environ.get("VT_DDP_BACKEND"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("VT_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -1,0 +1,138 @@
+"""Parity at BASELINE.json's full sizes (CogVideoX-2B 49x480x720: S = 17 776 tokens, d = 1920, hd = 64).
+The CPU oracle is exact here too: one attention head and one transformer block are small enough for fp32 on the
+host cores (chunked so the S x S matrices never exceed ~0.6 GB)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cogvideox_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+S_FULL = 17776
+
+
+def rb(x):
+    return x.to(BF).float()
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu(); b = b.detach().float().cpu()
+    return ((a - b).norm() / b.norm()).item(), ((a - b).abs().max() / b.abs().max()).item()
+
+
+def _attn_ref_chunked(q, k, v, do, scale, chunk=2048):
+    """fp32 reference for ONE head: returns o, lse (natural), dq, dk, dv with row-chunked S x S work."""
+    S = q.shape[0]
+    o = torch.empty_like(q); lse = torch.empty(S)
+    for i in range(0, S, chunk):
+        s = (q[i:i + chunk] @ k.T) * scale
+        lse[i:i + chunk] = torch.logsumexp(s, dim=1)
+        o[i:i + chunk] = torch.softmax(s, dim=1) @ v
+    delta = (o * do).sum(1)
+    dq = torch.empty_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    for i in range(0, S, chunk):
+        s = (q[i:i + chunk] @ k.T) * scale
+        p = torch.exp(s - lse[i:i + chunk, None])
+        dp = do[i:i + chunk] @ v.T
+        ds = p * (dp - delta[i:i + chunk, None])
+        dq[i:i + chunk] = (ds @ k) * scale
+        dk += (ds.T @ q[i:i + chunk]) * scale
+        dv += p.T @ do[i:i + chunk]
+    return o, lse, dq, dk, dv
+
+
+def test_attention_one_head_full_sequence(dev):
+    """forward + backward of one head at S = 17 776 against the exact fp32 reference (all rows, all outputs)."""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(17776)
+    S, H, B = S_FULL, 1, 1
+    sc2 = math.log2(math.e) / 8.0
+    q0 = torch.randn(S, 64, generator=g); k = rb(torch.randn(S, 64, generator=g)); v = rb(torch.randn(S, 64, generator=g))
+    q_dev = rb(q0 * sc2)                         # what vt_qk_layernorm_fwd(q_scale) would hand to the kernels
+    q = q_dev / sc2                              # the exact unscaled q the kernels therefore see
+    do = rb(torch.randn(S, 64, generator=g))
+    o_ref, lse_ref, dq_ref, dk_ref, dv_ref = _attn_ref_chunked(q, k, v, do, 0.125)
+    qkv = torch.stack([q_dev, k, v], dim=1).reshape(1, S, 192).to(dev, BF)
+    qd, kd, vd = qkv[:, :, :64], qkv[:, :, 64:128], qkv[:, :, 128:]
+    o = torch.empty(1, S, 64, dtype=BF, device=dev); lse2 = torch.empty(1, 1, S, device=dev)
+    ops.attn_fwd(qd, kd, vd, o, lse2, B, H, S, q_prescaled=True)
+    l2, mx = relerr(o[0], o_ref)
+    assert l2 < 6e-3 and mx < 3e-2, (l2, mx)
+    assert (lse2[0, 0].cpu() * math.log(2.0) - lse_ref).abs().max() < 3e-3
+    # size-independent property: the softmax rows the kernel used sum to one  <=>  lse2 is consistent with O's scale
+    dq = torch.zeros(1, S, 64, device=dev); dk = torch.empty(1, S, 64, dtype=BF, device=dev); dv = torch.empty_like(dk)
+    delta = torch.empty(S, device=dev)
+    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(1, S, 64), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=True)
+    for name, got, ref in (("dq", dq[0], dq_ref), ("dk", dk[0], dk_ref), ("dv", dv[0], dv_ref)):
+        l2, mx = relerr(got, ref)
+        assert l2 < 1.5e-2 and mx < 5e-2, (name, l2, mx)
+    # linearity of the backward in dO (size independent): bwd(2 dO) == 2 bwd(dO) up to bf16 rounding of the outputs
+    dq2 = torch.zeros_like(dq); dk2 = torch.empty_like(dk); dv2 = torch.empty_like(dv)
+    ops.attn_bwd(qd, kd, vd, o, (2 * do).to(dev, BF).view(1, S, 64), lse2, delta, dq2, dk2, dv2, B, H, S, q_prescaled=True)
+    assert relerr(dq2, 2 * dq)[0] < 2e-3 and relerr(dv2.float(), 2 * dv.float())[0] < 8e-3
+
+
+def test_gemm_full_block_shape(dev):
+    """the fused-QKV projection shape of the benchmark (M = 17 776 ragged, N = 5760, K = 1920 + 64) against fp32 matmul."""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = S_FULL, 5760, 1984
+    a = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) * 0.02); b = rb(torch.randn(N, generator=g))
+    ref = a @ w.T + b
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.gemm(a.to(dev, BF), w.to(dev, BF), out, b.to(dev, BF))
+    l2, mx = relerr(out, ref)
+    assert l2 < 4e-3 and mx < 2e-2, (l2, mx)
+    # checksum-of-checksums: column sums of the bf16 result against column sums of the reference
+    cs = out.float().sum(0).cpu(); cr = ref.sum(0)
+    assert ((cs - cr).abs() / (ref.abs().sum(0) + 1e-6)).max() < 2e-3
+
+
+def test_one_full_size_block_train_step(dev):
+    """CogVideoX-2B dimensions (d 1920, 30 heads, S 17 776, text 226 x 4096) with ONE transformer block: loss and every
+    LoRA gradient against the fp32 oracle on the same bf16-rounded weights."""
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.lora import LoraConfig, get_peft_model
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.selfcheck import oracle_params
+    from vt355.workflow import _LossFn
+    cfg = O.DiTConfig(num_layers=1)
+    model = CogVideoXTransformer3DModel(num_layers=1).init_weights(3).to(dev)
+    model.requires_grad_(False)
+    peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
+    st = peft._lora_state
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p, (layer, kind, j) in zip(st.params, st._index):
+            if kind == "B":
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
+    st.mark_changed()
+    x0 = torch.randn(1, 13, 16, 60, 90, generator=g)
+    text = (torch.randn(1, 226, 4096, generator=g) * 0.2).to(BF)
+    noise = torch.randn(x0.shape, generator=g)
+    t = torch.tensor([437])
+    sched = CogVideoXDPMScheduler()
+    noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
+    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    sa, sb, w = sched.coefficients(t.to(dev))
+    loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
+    st.grad.zero_(); loss.backward()
+    P, Lo = oracle_params(model, st)
+    for v in Lo.values():
+        v.requires_grad_(True)
+    abar = O.alphas_cumprod_cogvideox().float()
+    nref = noisy.float().cpu()
+    out_ref = O.dit_forward(P, cfg, nref, text.float(), t, Lo, st.scaling)
+    pred = O.get_velocity(out_ref, nref, t, abar)
+    loss_ref = torch.mean(((1 / (1 - abar[t])).view(-1, 1, 1, 1, 1) * (pred - x0) ** 2).reshape(1, -1), dim=1).mean()
+    loss_ref.backward()
+    assert relerr(out, out_ref)[0] < 2e-2
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-2, (loss.item(), loss_ref.item())
+    gref = torch.cat([Lo[k].grad.reshape(-1) for k in Lo])
+    gdev = torch.cat([st.view(st.grad, l, kd, j).reshape(-1).cpu() for (l, kd, j) in st._index])
+    cos = F.cosine_similarity(gdev, gref, dim=0).item()
+    l2 = ((gdev - gref).norm() / gref.norm()).item()
+    assert cos > 0.995 and l2 < 0.1, (cos, l2)

@@ -153,6 +153,18 @@ def main():
                 kern[name]["tflops_algorithmic"] = alg[name] / ms / 1e9
         dom = "attn_bwd"
         ach = kern[dom]["tflops_algorithmic"] if dom in kern else None
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the figure
+        # comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh), corrected as
+        # MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, KiB units).
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")) as f:
+                tr = json.load(f)["traffic"]
+            key = [k for k in tr if "attn_bwd_hd64_kernel" in k][0]
+            if args.micro_batch == 2 and args.layers == 30:
+                traffic = tr[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "finetune samples/sec, CogVideoX-2B T2V LoRA 49x480x720 bf16", "value": samples / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +177,9 @@ def main():
                        "parallelism": f"dp{world}", "recompute": "none (activations kept in HBM)",
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": None,
+                         "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_summary.json; "
+                                         "18.9 GB of it are the fp32 dQ atomics, algorithmic bytes are 1.1 GB)",
                          "note": "algorithmic FLOPs per launch 8*S^2*d*B (dQ,dK,dV products; P recompute not counted)"},
             "kernels": kern,
             "loss_last": loss_vals[-1], "loss_first": loss_vals[0],

@@ -1,0 +1,34 @@
+#!/bin/bash
+# HBM traffic + kernel stats of the bench command (separate rocprofv3 passes; --pmc never combined with tracing domains).
+# usage on the GPU box from the repo root:  bash tools/pmc_bench.sh gpurun_out/pmc_bench
+set -e
+export TMPDIR=/tmp
+OUT=${1:-gpurun_out/pmc_bench}
+mkdir -p $OUT
+CMD="python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, json, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, d in agg.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)
+        res[k] = {"launches": len(d["FETCH_SIZE"]), "fetch_kib_raw": f, "write_kib": w,
+                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+stats = {}
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        stats[r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
+json.dump({"traffic": res, "kernel_stats": stats}, open(out + "/summary.json", "w"), indent=1)
+for k in sorted(res, key=lambda k: -res[k]["hbm_bytes_per_launch"] * res[k]["launches"])[:8]:
+    print(k[:60], res[k])
+PY

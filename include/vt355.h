@@ -34,7 +34,7 @@ const char* vt_error_string(int code);
 /* GEMM epilogues */
 #define VT_EPI_BIAS 0        /* C = A W^T + bias                                   (nn.Linear)                */
 #define VT_EPI_BIAS_GELU 1   /* C2 = u = A W^T + bias ; C = gelu_tanh(u)           (FeedForward net.0)         */
-#define VT_EPI_GATED_RES 2   /* C = R + gate[b,seg] * (A W^T + bias)               (h += gate * to_out / ff.net.2;
+#define VT_EPI_GATED_RES 2   /* C = R + gate[b,seg] * (A W^T + bias); C2 (optional) = A W^T + bias   (h += gate * to_out / ff.net.2;
                                                                                     gate == NULL -> C = R + ...;
                                                                                     r_mod > 0 -> R row = m % r_mod) */
 #define VT_EPI_DGELU 3       /* C = (A W^T) * gelu_tanh'(U)                        (backward through net.0 act) */
@@ -49,6 +49,31 @@ int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ld
                  const void* R, int ldr, int r_mod,
                  const float* gate_txt, const float* gate_vid, int gate_bstride, int S, int St,
                  void* C2, int ldc2, const void* U, int ldu, void* stream);
+
+/* Weight-gradient GEMM: C[P,Q] (+)= alpha * sum_m A[m,P] * B[m,Q]  (A = dY [M,lda], B = X [M,ldb] bf16, C fp32).
+ * P % 128 == 0, Q % 128 == 0.  Replaces: autograd's dW = dY^T X of every nn.Linear (full fine-tuning, config 3). */
+int vt_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int P, int Q,
+                    float alpha, int accumulate, void* stream);
+
+/* out1[g,d] += sum_m X[m,d];  out2[g,d] += sum_m X[m,d]*Yn[m,d]  (Yn = Y, or (Y-mean[m])*rstd[m] with row stats);
+ * grouped: the sums of (sample b, seg 0 text / 1 video) go to out + b*o_bstride + seg*o_segstride + d.
+ * Bias / adaLN / LayerNorm parameter gradients. */
+int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, const float* mean, const float* rstd,
+                    float* out1, float* out2, long long M, int D, int S, int St, int grouped,
+                    long long o_bstride, long long o_segstride, void* stream);
+
+/* dgamma/dbeta [2][2][64] (q: gamma,beta; k: gamma,beta) of the per-head LayerNorm, accumulated */
+int vt_qk_ln_param_grads(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
+                         const float* mean, const float* rstd, float* out_2x2x64, long long M, int H, void* stream);
+/* LayerNorm / adaLN parameter gradients from grouped sums G1 = sum dy, G2 = sum dy*xhat (see csrc/reduce.hip) */
+int vt_ln_param_combine(const float* G1, const float* G2, int G, int D, const void* gamma, const void* beta,
+                        const float* scale_txt, const float* scale_vid, int bstride, float* dgamma, float* dbeta,
+                        float* dshift_txt, float* dshift_vid, float* dscale_txt, float* dscale_vid, int dbstride,
+                        int grouped, void* stream);
+/* Linear backward for <= 8 rows: dW += dy^T x, db += sum dy, dx += dy W  (time-embedding / adaLN MLPs) */
+int vt_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, float* dW, float* db,
+                        float* dx, int lddx, int Bn, int N, int K, void* stream);
+int vt_silu_bwd(const float* dy, const void* x, float* dx, long long n, void* stream);
 
 /* Flash attention forward, head_dim 64, non-causal.  Element (b,s,h,d) of q lives at
  * q + b*q_bs + s*q_rs + h*64 + d (same for k, v, o) so a fused QKV projection is consumed in place.

@@ -294,3 +294,36 @@ def test_lora_kernels(dev):
     WT = torch.full((K + 64, 3 * N), 7.0, dtype=BF, device=dev)
     ops.lora_pack_bt(Bc.to(dev), WT[K:], 3 * N, 3, N, r, 0.25)
     close(WT[K:], ref.T, 1e-2, 1e-3, "pack_bt")
+
+
+# ------------------------------------------------------------------ weight-gradient GEMM and column reductions (full fine-tune)
+@pytest.mark.parametrize("M,P,Q", [(200, 128, 128), (1000, 256, 384), (17776, 1920, 1920), (129, 384, 128)])
+def test_gemm_nt(dev, M, P, Q):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + P)
+    a = rb(torch.randn(M, P + 64, generator=g)); b = rb(torch.randn(M, Q + 8, generator=g))     # strided operands
+    ref = a[:, :P].T @ b[:, :Q]
+    c = torch.full((P, Q), 3.0, device=dev)
+    ops.gemm_nt(a.to(dev, BF), b.to(dev, BF), c, P=P, Q=Q, alpha=0.5, accumulate=True)
+    close(c, 3.0 + 0.5 * ref, 2e-3, 2e-3 * ref.abs().max().item(), "gemm_nt accumulate")
+    ops.gemm_nt(a.to(dev, BF), b.to(dev, BF), c, P=P, Q=Q, alpha=1.0, accumulate=False)
+    close(c, ref, 2e-3, 2e-3 * ref.abs().max().item(), "gemm_nt overwrite")
+
+
+def test_group_colsum(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(21)
+    B, S, St, D = 3, 301, 17, 192
+    M = B * S
+    x = rb(torch.randn(M, D, generator=g)); y = rb(torch.randn(M, D, generator=g) * 2 + 1)
+    mean = y.mean(1); rstd = 1.0 / (y.var(1, unbiased=False) + 1e-5).sqrt()
+    o1 = torch.zeros(1, D, device=dev)
+    ops.group_colsum(x.to(dev, BF), o1)
+    close(o1[0], x.sum(0), 1e-4, 1e-3, "colsum")
+    o1 = torch.zeros(2 * B, D, device=dev); o2 = torch.zeros(2 * B, D, device=dev)
+    ops.group_colsum(x.to(dev, BF), o1, y=y.to(dev, BF), out2=o2, mean=mean.to(dev), rstd=rstd.to(dev), S=S, St=St, grouped=True)
+    yn = (y - mean[:, None]) * rstd[:, None]
+    for b in range(B):
+        for seg, rows in ((0, slice(b * S, b * S + St)), (1, slice(b * S + St, (b + 1) * S))):
+            close(o1[2 * b + seg], x[rows].sum(0), 1e-4, 2e-3, "group sum")
+            close(o2[2 * b + seg], (x[rows] * yn[rows]).sum(0), 1e-4, 3e-3, "group sum of products")

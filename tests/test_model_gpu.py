@@ -72,3 +72,77 @@ def test_grad_accumulation_and_state_dict_filter(dev):
     sd = peft.state_dict()
     lora_keys = [k for k in sd if "lora" in k]
     assert len(lora_keys) == 2 * 4 * cfg.num_layers and all(k.startswith("base_model.model.") for k in lora_keys)
+
+
+def test_full_finetune_all_parameter_grads_match_oracle(dev):
+    """BASELINE config 3 (every weight trainable): loss and ALL parameter gradients of a tiny DiT against the fp64 oracle,
+    then one fused AdamW step against torch.optim.AdamW on the oracle's gradients."""
+    import cogvideox_oracle as O
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.fullft import enable_full_finetune
+    from vt355.optim import FusedAdamW
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.workflow import _LossFn
+    cfg = O.tiny_config()
+    kw = {k: getattr(cfg, k) for k in ("num_attention_heads", "attention_head_dim", "num_layers", "time_embed_dim", "text_embed_dim",
+                                       "sample_width", "sample_height", "sample_frames", "max_text_seq_length")}
+    model = CogVideoXTransformer3DModel(**kw).init_weights(11, std=0.05).to(dev)
+    ft = enable_full_finetune(model)
+    assert all(p.requires_grad for p in model.parameters())
+    g = torch.Generator().manual_seed(77)
+    B, Fr = 2, (cfg.sample_frames - 1) // 4 + 1
+    x0 = torch.randn(B, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g)
+    text = (torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g) * 0.5).to(torch.bfloat16)
+    noise = torch.randn(x0.shape, generator=g)
+    t = torch.tensor([150, 650])
+    sched = CogVideoXDPMScheduler()
+    noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
+    out = model(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    sa, sb, w = sched.coefficients(t.to(dev))
+    loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
+    ft.grad.zero_()
+    loss.backward()
+    # oracle on the same bf16-rounded weights, fp64
+    Pref = {k: v.detach().float().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    abar = O.alphas_cumprod_cogvideox()
+    nref = noisy.float().cpu().double()
+    out_ref = O.dit_forward(Pref, cfg, nref, text.double(), t)
+    pred = O.get_velocity(out_ref, nref, t, abar)
+    wref = (1.0 / (1.0 - abar[t])).view(-1, 1, 1, 1, 1)
+    loss_ref = torch.mean((wref * (pred - x0.double()) ** 2).reshape(B, -1), dim=1).mean()
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 2e-2
+    bad = []
+    for name in ft.names:
+        gd = ft.g(name).cpu().double().reshape(-1)
+        gr = Pref[name].grad.reshape(-1)
+        if name.endswith("norm_k.bias"):
+            # adding a constant to every key shifts all scores of a query equally: softmax is invariant and the exact
+            # gradient is 0 (the oracle returns fp64 noise) -> the device value must be noise-sized, not "aligned"
+            assert gr.norm() < 1e-9
+            assert gd.norm() < 0.05 * ft.g(name.replace("bias", "weight")).norm().item(), name
+            continue
+        cos = torch.nn.functional.cosine_similarity(gd, gr, dim=0).item()
+        rel = ((gd - gr).norm() / (gr.norm() + 1e-30)).item()
+        if not (cos > 0.99 and rel < 0.15):
+            bad.append((name, round(cos, 4), round(rel, 4)))
+    assert not bad, bad[:12]
+    # whole-gradient agreement
+    gd = ft.grad.cpu().double()
+    gr = torch.cat([Pref[n].grad.reshape(-1) for n in ft.names])
+    assert torch.nn.functional.cosine_similarity(gd, gr, dim=0).item() > 0.999, torch.nn.functional.cosine_similarity(gd, gr, dim=0).item()
+    # optimizer: fused AdamW over the flat fp32 master == torch.optim.AdamW fed the SAME (device) gradients
+    master = ft.flat.clone().cpu()
+    pt = master.clone().requires_grad_(True)
+    topt = torch.optim.AdamW([pt], lr=1e-3)
+    pt.grad = ft.grad.clone().cpu()
+    topt.step()
+    opt = FusedAdamW(ft.params, lr=1e-3, fullft_state=ft)
+    v0 = ft.version
+    opt.step()
+    assert ft.version == v0 + 1
+    assert (ft.flat.cpu() - pt.detach()).abs().max().item() < 1e-5
+    assert (ft.flat_bf16.float().cpu() - pt.detach()).abs().max().item() < 2e-2 * pt.detach().abs().max().item()
+    # the packed transposed operands follow the new weights at the next forward
+    out2 = model(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    assert torch.isfinite(out2.float()).all() and not torch.equal(out2, out)

@@ -40,6 +40,12 @@ def main():
                 pre = torch.empty(M, N, dtype=BF, device=dev)
                 med, mn = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))
                 print(f"   +gelu epilogue: {med:.3f} ms {2.0*M*N*K/med/1e9:.0f} TF/s", flush=True)
+    if "nt" in which:
+        for (M, P, Q, name) in [(S, 5760, 1920, "dW_qkv"), (S, 7680, 1920, "dW_ff1"), (S, 1920, 7680, "dW_ff2"), (2 * S, 5760, 1920, "dW_qkv_B2")]:
+            a = torch.randn(M, P, device=dev).to(BF); b = torch.randn(M, Q, device=dev).to(BF)
+            c = torch.zeros(P, Q, device=dev)
+            med, mn = timeit(lambda: ops.gemm_nt(a, b, c))
+            print(f"gemm_nt {name:9s} M={M} P={P} Q={Q}: {med:.3f} ms  {2.0*M*P*Q/med/1e9:.0f} TF/s", flush=True)
     if "attn" in which:
         B = 1
         qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)

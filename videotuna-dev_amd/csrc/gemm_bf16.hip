@@ -211,6 +211,12 @@ __global__ __launch_bounds__(256, 2) void GEMM_KERNEL(GemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
                 } else if (EPI == EPI_GATED_RES) {
+                    if (p.C2 != nullptr) {           // branch output before gating (full fine-tune: d gate = sum dh * branch)
+                        u32x2 u2;
+                        u2[0] = pack2(o[0], o[1]);
+                        u2[1] = pack2(o[2], o[3]);
+                        *(u32x2*)(p.C2 + (size_t)m * p.ldc2 + n) = u2;
+                    }
                     const int rr = p.r_mod > 0 ? (m % p.r_mod) : m;
                     u32x2 r2 = *(const u32x2*)(p.R + (size_t)rr * p.ldr + n);
                     float r[4] = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
@@ -279,6 +285,7 @@ extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* 
             return VT_CAT(launch, VT_SUFFIX)<EPI_BIAS_GELU, false>(p, st);
         case EPI_GATED_RES:
             if (out_fp32 || R == nullptr || (ldr % 4) || !VT_CAT(al16, VT_SUFFIX)(R)) return VT_ERR_BAD_SHAPE;
+            if (C2 != nullptr && ((ldc2 % 4) || !VT_CAT(al16, VT_SUFFIX)(C2))) return VT_ERR_BAD_SHAPE;
             if (gate_vid != nullptr && (gate_txt == nullptr || (gate_bstride % 4) || !VT_CAT(al16, VT_SUFFIX)(gate_vid) || !VT_CAT(al16, VT_SUFFIX)(gate_txt)))
                 return VT_ERR_BAD_SHAPE;
             return VT_CAT(launch, VT_SUFFIX)<EPI_GATED_RES, false>(p, st);

@@ -1,0 +1,253 @@
+// Column reductions over the token axis (parameter gradients that are sums over rows), gfx950, HBM-bound.
+//
+//   out1[g, d] (+)= sum_{m in group g} X[m, d]
+//   out2[g, d] (+)= sum_{m in group g} X[m, d] * Yn[m, d]      (optional)
+// with Yn = Y, or Yn = (Y - mean[m]) * rstd[m] when row statistics are given (the normalised LayerNorm input).
+// group = none, or (b(m), seg(m)) with seg 0 = text rows, 1 = video rows (adaLN modulation is per sample and per
+// segment); a group's sums go to out + b*o_bstride + seg*o_segstride + d (strides may be negative).  Used for: Linear bias grads (sum of dY), adaLN shift/scale/gate grads and LayerNorm
+// gamma/beta grads of diffusers' CogVideoXLayerNormZero / AdaLayerNorm (SURVEY 8(a) a3,a6,a9) -- what autograd's
+// backward of those modules reduces to.
+// Grid: (column blocks of 512, row slices); a block of 128 threads walks its slice 8 rows at a time (4 columns =
+// one 8-byte load per thread and row) and adds its partial sums with fp32 atomics (few slices -> few atomics).
+#include "common.h"
+
+#define RD_SLICES 64
+
+struct ReduceParams {
+    const bf16_t* X; int ldx;
+    const bf16_t* Y; int ldy;
+    const float* mean; const float* rstd;
+    float* out1; float* out2;
+    long long M; int D, S, St, grouped;
+    long long o_bstride, o_segstride;   // grouped output address: out + b*o_bstride + seg*o_segstride + d
+    int rows_per_slice;
+};
+
+__global__ __launch_bounds__(128) void group_colsum_kernel(ReduceParams p) {
+    const int col = (blockIdx.x * 128 + threadIdx.x) * 4;
+    if (col >= p.D) return;
+    long long m0 = (long long)blockIdx.y * p.rows_per_slice;
+    const long long m1 = (m0 + p.rows_per_slice) < p.M ? (m0 + p.rows_per_slice) : p.M;
+    while (m0 < m1) {
+        // rows [m0, me) all belong to one group
+        long long gidx = 0;
+        long long me = m1;
+        if (p.grouped) {
+            const long long b = m0 / p.S;
+            const long long s = m0 - b * p.S;
+            const int seg = s < p.St ? 0 : 1;
+            gidx = b * p.o_bstride + seg * p.o_segstride;
+            const long long gend = b * p.S + (seg == 0 ? p.St : p.S);
+            me = gend < m1 ? gend : m1;
+        }
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (long long m = m0; m < me; m += 8) {
+            u32x2 xr[8], yr[8];
+            float mu[8], rs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long mm = (m + u) < me ? (m + u) : (me - 1);
+                xr[u] = *(const u32x2*)(p.X + (size_t)mm * p.ldx + col);
+                if (p.Y != nullptr) yr[u] = *(const u32x2*)(p.Y + (size_t)mm * p.ldy + col);
+                if (p.mean != nullptr) { mu[u] = p.mean[mm]; rs[u] = p.rstd[mm]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (m + u < me) {
+                    const float x[4] = {__uint_as_float(xr[u][0] << 16), __uint_as_float(xr[u][0] & 0xffff0000u),
+                                        __uint_as_float(xr[u][1] << 16), __uint_as_float(xr[u][1] & 0xffff0000u)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a1[j] += x[j];
+                    if (p.Y != nullptr) {
+                        float y[4] = {__uint_as_float(yr[u][0] << 16), __uint_as_float(yr[u][0] & 0xffff0000u),
+                                      __uint_as_float(yr[u][1] << 16), __uint_as_float(yr[u][1] & 0xffff0000u)};
+                        if (p.mean != nullptr) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) y[j] = (y[j] - mu[u]) * rs[u];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a2[j] += x[j] * y[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p.out1 != nullptr) atomicAdd(p.out1 + gidx + col + j, a1[j]);
+            if (p.out2 != nullptr) atomicAdd(p.out2 + gidx + col + j, a2[j]);
+        }
+        m0 = me;
+    }
+}
+
+extern "C" int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, const float* mean, const float* rstd,
+                               float* out1, float* out2, long long M, int D, int S, int St, int grouped,
+                               long long o_bstride, long long o_segstride, void* stream) {
+    if (M <= 0 || D <= 0 || (D % 4) || (ldx % 4) || (Y != nullptr && (ldy % 4))) return VT_ERR_BAD_SHAPE;
+    if (out2 != nullptr && Y == nullptr) return VT_ERR_BAD_SHAPE;
+    if (grouped && (S <= 0 || St < 0 || St > S)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)X) | ((uintptr_t)Y)) & 7) return VT_ERR_BAD_ALIGN;
+    ReduceParams p{(const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, mean, rstd, out1, out2, M, D, S > 0 ? S : 1, St, grouped,
+                   o_bstride, o_segstride, 0};
+    p.rows_per_slice = (int)((M + RD_SLICES - 1) / RD_SLICES);
+    dim3 grid((D + 511) / 512, RD_SLICES);
+    hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(128), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-head LayerNorm(64) parameter gradients of q and k:
+//   dgamma[which][e] += sum_{m,h} dY[m,which,h,e] * xhat[m,which,h,e],   dbeta[which][e] += sum_{m,h} dY[...]
+// dq_hat is fp32 (attention-backward accumulation buffer), dk_hat bf16.  out: [2][2][64] = (q:gamma,beta ; k:gamma,beta)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_ln_param_grads_kernel(const float* dqh, int lddq, const bf16_t* dkh, int lddk,
+                                                               const bf16_t* qkv, int ld, const float* mean, const float* rstd,
+                                                               float* out, long long M, int H) {
+    __shared__ float red[4][2][2][64];       // [wave][which][gamma/beta][e]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 7;                // 8 lanes per 64-element group
+    const int gl = lane >> 3;                // 8 groups per wave pass
+    float ag[2][8], ab[2][8];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ag[w][j] = 0.f; ab[w][j] = 0.f; }
+    const long long total = M * 2 * H;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long grp = (long long)blockIdx.x * 32 + wave * 8 + gl; grp < total; grp += stride) {
+        const long long m = grp / (2 * H);
+        const int wh = (int)(grp % (2 * H));
+        const bool isk = wh >= H;
+        const float mu = mean[m * 2 * H + wh], rs = rstd[m * 2 * H + wh];
+        float dy[8], xv[8];
+        if (isk) unpack8(*(const u32x4*)(dkh + (size_t)m * lddk + (wh - H) * 64 + sub * 8), dy);
+        else {
+            const float* src = dqh + (size_t)m * lddq + wh * 64 + sub * 8;
+            f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dy[j] = a[j]; dy[j + 4] = b[j]; }
+        }
+        unpack8(*(const u32x4*)(qkv + (size_t)m * ld + wh * 64 + sub * 8), xv);
+        const int w = isk ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ag[w][j] += dy[j] * (xv[j] - mu) * rs; ab[w][j] += dy[j]; }
+    }
+    // reduce the 8 groups of a wave that share `sub` (lanes sub, sub+8, ...): xor 8, 16, 32
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = ag[w][j], b = ab[w][j];
+            a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (lane < 8) { red[wave][w][0][sub * 8 + j] = a; red[wave][w][1][sub * 8 + j] = b; }
+        }
+    __syncthreads();
+    // 256 threads = [which 2][gb 2][e 64]
+    const int w = tid >> 7, gb = (tid >> 6) & 1, e = tid & 63;
+    atomicAdd(out + (w * 2 + gb) * 64 + e, red[0][w][gb][e] + red[1][w][gb][e] + red[2][w][gb][e] + red[3][w][gb][e]);
+}
+extern "C" int vt_qk_ln_param_grads(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
+                                    const float* mean, const float* rstd, float* out_2x2x64, long long M, int H, void* stream) {
+    if (M <= 0 || H <= 0 || (ld % 8) || (lddq % 4) || (lddk % 8)) return VT_ERR_BAD_SHAPE;
+    long long groups = M * 2 * H;
+    int blocks = (int)((groups + 31) / 32 > 1024 ? 1024 : (groups + 31) / 32);
+    hipLaunchKernelGGL(qk_ln_param_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dq_hat, lddq, (const bf16_t*)dk_hat,
+                       lddk, (const bf16_t*)qkv, ld, mean, rstd, out_2x2x64, M, H);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm + adaLN parameter gradients from the grouped sums G1 = sum dy, G2 = sum dy*xhat  ([G, D] fp32, G groups):
+//   dgamma[d] += sum_g (1 + scale_g[d]) G2[g,d]        dbeta[d] += sum_g (1 + scale_g[d]) G1[g,d]
+//   dshift_g[d] += G1[g,d]                               dscale_g[d] += gamma[d] G2[g,d] + beta[d] G1[g,d]
+// scale_g / dshift_g / dscale_g are addressed as base_{seg} + b * bstride (seg = g & 1: 0 text, 1 video; b = g >> 1).
+// Null pointers skip the corresponding output (no modulation / no affine).
+// ------------------------------------------------------------------------------------------------
+__global__ void ln_param_combine_kernel(const float* G1, const float* G2, int G, int D, const bf16_t* gamma, const bf16_t* beta,
+                                        const float* scale_txt, const float* scale_vid, int bstride,
+                                        float* dgamma, float* dbeta, float* dshift_txt, float* dshift_vid, float* dscale_txt,
+                                        float* dscale_vid, int dbstride, int grouped) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const float ga = gamma ? bf2f(gamma[d]) : 1.f, be = beta ? bf2f(beta[d]) : 0.f;
+    float dg = 0.f, db = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float g1 = G1[(size_t)g * D + d], g2 = G2[(size_t)g * D + d];
+        float sc1 = 1.f;
+        const int b = grouped ? (g >> 1) : g, seg = grouped ? (g & 1) : 1;
+        if (scale_vid != nullptr) sc1 += (seg ? scale_vid : scale_txt)[(size_t)b * bstride + d];
+        dg += sc1 * g2; db += sc1 * g1;
+        if (dshift_vid != nullptr) {
+            (seg ? dshift_vid : dshift_txt)[(size_t)b * dbstride + d] += g1;
+            (seg ? dscale_vid : dscale_txt)[(size_t)b * dbstride + d] += ga * g2 + be * g1;
+        }
+    }
+    if (dgamma != nullptr) { dgamma[d] += dg; dbeta[d] += db; }
+}
+extern "C" int vt_ln_param_combine(const float* G1, const float* G2, int G, int D, const void* gamma, const void* beta,
+                                   const float* scale_txt, const float* scale_vid, int bstride, float* dgamma, float* dbeta,
+                                   float* dshift_txt, float* dshift_vid, float* dscale_txt, float* dscale_vid, int dbstride,
+                                   int grouped, void* stream) {
+    if (G <= 0 || D <= 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(ln_param_combine_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, G1, G2, G, D,
+                       (const bf16_t*)gamma, (const bf16_t*)beta, scale_txt, scale_vid, bstride, dgamma, dbeta, dshift_txt,
+                       dshift_vid, dscale_txt, dscale_vid, dbstride, grouped);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of a Linear applied to a handful of rows (the time-embedding / adaLN MLPs see one row per sample):
+//   dW[n,k] += sum_b dy[b,n] x[b,k] ;  db[n] += sum_b dy[b,n] ;  dx[b,k] += sum_n dy[b,n] W[n,k]      (Bn <= 8)
+// dy fp32 [Bn, ldy], x bf16 [Bn, ldx], W bf16 [N, K].  One block per 64 output rows n.
+// ------------------------------------------------------------------------------------------------
+#define SL_MAXB 8
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* dy, int ldy, const bf16_t* x, int ldx, const bf16_t* W,
+                                                              float* dW, float* db, float* dx, int lddx, int Bn, int N, int K) {
+    const int n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    __shared__ float sdy[SL_MAXB][64];
+    for (int i = tid; i < Bn * 64; i += 256) {
+        const int b = i >> 6, nn = i & 63;
+        sdy[b][nn] = (n0 + nn < N) ? dy[(size_t)b * ldy + n0 + nn] : 0.f;
+    }
+    __syncthreads();
+    if (db != nullptr && tid < 64 && n0 + tid < N) {
+        float s = 0.f;
+        for (int b = 0; b < Bn; ++b) s += sdy[b][tid];
+        db[n0 + tid] += s;
+    }
+    for (int k = tid; k < K; k += 256) {
+        float xv[SL_MAXB], dxa[SL_MAXB];
+        for (int b = 0; b < Bn; ++b) { xv[b] = bf2f(x[(size_t)b * ldx + k]); dxa[b] = 0.f; }
+        for (int nn = 0; nn < 64 && n0 + nn < N; ++nn) {
+            const float w = bf2f(W[(size_t)(n0 + nn) * K + k]);
+            float g = 0.f;
+            for (int b = 0; b < Bn; ++b) { g += sdy[b][nn] * xv[b]; dxa[b] += sdy[b][nn] * w; }
+            if (dW != nullptr) dW[(size_t)(n0 + nn) * K + k] += g;
+        }
+        if (dx != nullptr)
+            for (int b = 0; b < Bn; ++b) atomicAdd(dx + (size_t)b * lddx + k, dxa[b]);
+    }
+}
+extern "C" int vt_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, float* dW, float* db,
+                                   float* dx, int lddx, int Bn, int N, int K, void* stream) {
+    if (Bn <= 0 || Bn > SL_MAXB || N <= 0 || K <= 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, ldy, (const bf16_t*)x, ldx,
+                       (const bf16_t*)W, dW, db, dx, lddx, Bn, N, K);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// dx = dy * silu'(x)  (fp32 dy/dx, bf16 pre-activation x)
+__global__ void silu_bwd_kernel(const float* dy, const bf16_t* x, float* dx, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = bf2f(x[i]);
+    const float s = 1.0f / (1.0f + __expf(-v));
+    dx[i] = dy[i] * (s * (1.0f + v * (1.0f - s)));
+}
+extern "C" int vt_silu_bwd(const float* dy, const void* x, float* dx, long long n, void* stream) {
+    if (n <= 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)x, dx, n);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -161,6 +161,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self._packed = None           # engine operands, built lazily from the parameters
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
         self.lora = None              # set by vt355.lora.inject
+        self.fullft = None            # set by vt355.fullft.enable_full_finetune
 
     # ----- HF-like surface -----
     @property
@@ -214,6 +215,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         return model
 
     def _apply(self, fn, *a, **k):
+        if getattr(self, "fullft", None) is not None:
+            raise RuntimeError("move / convert the model BEFORE enable_full_finetune(): its parameters are views of one flat buffer")
         out = super()._apply(fn, *a, **k)
         self._packed = None
         self._pos_cache = {}

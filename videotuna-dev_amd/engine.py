@@ -45,21 +45,31 @@ def _ext_t(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack(model) -> SimpleNamespace:
-    if any(p.requires_grad for n, p in model.named_parameters() if "lora" not in n):
-        raise NotImplementedError("full fine-tuning of the base weights is not built yet in this engine "
-                                  "(LoRA finetune is); freeze the base with requires_grad_(False)")
+    ft = getattr(model, "fullft", None)
+    if ft is None and any(p.requires_grad for n, p in model.named_parameters() if "lora" not in n):
+        raise RuntimeError("base weights require grad but no training state exists: call vt355.fullft.enable_full_finetune(model) "
+                           "for full fine-tuning, or freeze the base (requires_grad_(False)) and inject LoRA adapters")
     for n, p in model.named_parameters():
         if "lora" not in n and p.dtype != BF16:
             raise TypeError(f"parameter {n} is {p.dtype}; the MI355X engine computes in bf16 -- call .bfloat16()")
-    P = SimpleNamespace(layers=[], lora_version=-1)
+    P = SimpleNamespace(layers=[], lora_version=-1, ft_version=-1 if ft is None else ft.version)
+    d = model.inner_dim
     with torch.no_grad():
-        for blk in model.transformer_blocks:
+        for i, blk in enumerate(model.transformer_blocks):
             a = blk.attn1
             wq, bq = _lin(a.to_q); wk, bk = _lin(a.to_k); wv, bv = _lin(a.to_v); wo, bo = _lin(a.to_out[0])
-            wqkv = torch.cat([wq, wk, wv], 0)
             L = SimpleNamespace()
-            L.w_qkv = _ext_rows(wqkv); L.b_qkv = torch.cat([bq, bk, bv]).contiguous(); L.w_qkv_t = _ext_t(wqkv)
-            L.w_o = _ext_rows(wo); L.b_o = bo; L.w_o_t = _ext_t(wo)
+            if ft is not None:
+                # q|k|v weights / biases are adjacent in the flat buffer: the fused operand is a VIEW (no copy, no K-extension)
+                pre = f"transformer_blocks.{i}.attn1."
+                L.w_qkv = ft.span(ft.flat_bf16, pre + "to_q.weight", pre + "to_v.weight", (3 * d, d))
+                L.b_qkv = ft.span(ft.flat_bf16, pre + "to_q.bias", pre + "to_v.bias", (3 * d,))
+                L.w_qkv_t = L.w_qkv.t().contiguous()
+                L.w_o, L.b_o, L.w_o_t = wo, bo, wo.t().contiguous()
+            else:
+                wqkv = torch.cat([wq, wk, wv], 0)
+                L.w_qkv = _ext_rows(wqkv); L.b_qkv = torch.cat([bq, bk, bv]).contiguous(); L.w_qkv_t = _ext_t(wqkv)
+                L.w_o = _ext_rows(wo); L.b_o = bo; L.w_o_t = _ext_t(wo)
             w1, b1 = _lin(blk.ff.net[0].proj); w2, b2 = _lin(blk.ff.net[2])
             L.w1, L.b1, L.w1_t = w1, b1, w1.t().contiguous()
             L.w2, L.b2, L.w2_t = w2, b2, w2.t().contiguous()
@@ -67,10 +77,17 @@ def pack(model) -> SimpleNamespace:
             L.n2g, L.n2b = blk.norm2.norm.weight, blk.norm2.norm.bias
             L.gq, L.bq, L.gk, L.bk = a.norm_q.weight, a.norm_q.bias, a.norm_k.weight, a.norm_k.bias
             P.layers.append(L)
-        ada_w = [m.linear.weight for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
-        ada_b = [m.linear.bias for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
-        P.w_ada = torch.cat(ada_w + [model.norm_out.linear.weight], 0).contiguous()
-        P.b_ada = torch.cat(ada_b + [model.norm_out.linear.bias], 0).contiguous()
+        if ft is not None:
+            nl = model.config.num_layers
+            nmod = (12 * nl + 2) * d
+            P.w_ada = ft.span(ft.flat_bf16, "transformer_blocks.0.norm1.linear.weight", "norm_out.linear.weight",
+                              (nmod, model.config.time_embed_dim))
+            P.b_ada = ft.span(ft.flat_bf16, "transformer_blocks.0.norm1.linear.bias", "norm_out.linear.bias", (nmod,))
+        else:
+            ada_w = [m.linear.weight for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
+            ada_b = [m.linear.bias for blk in model.transformer_blocks for m in (blk.norm1, blk.norm2)]
+            P.w_ada = torch.cat(ada_w + [model.norm_out.linear.weight], 0).contiguous()
+            P.b_ada = torch.cat(ada_b + [model.norm_out.linear.bias], 0).contiguous()
         pw = model.patch_embed.proj.weight
         P.patch_w = pw.reshape(pw.shape[0], -1).contiguous()            # [d, C*p*p]  (c p q)
         P.patch_b = model.patch_embed.proj.bias
@@ -83,8 +100,9 @@ def pack(model) -> SimpleNamespace:
 
 
 def packed(model) -> SimpleNamespace:
-    if model._packed is None:
-        model._packed = pack(model)
+    ft = getattr(model, "fullft", None)
+    if model._packed is None or (ft is not None and model._packed.ft_version != ft.version):
+        model._packed = pack(model)          # full fine-tune: the transposed operand copies follow the updated weights
     P = model._packed
     st = model.lora
     if st is not None and P.lora_version != st.version:
@@ -119,6 +137,7 @@ def run_forward(model, x, text, t, save: bool):
     S = St + Sv
     M = B * S
     dev = x.device
+    ft = getattr(model, "fullft", None)
     KE = d + EXT if st is not None else d        # GEMM reduction length on the LoRA-extended operands
     r3 = 3 * st.r if st is not None else 0
     E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
@@ -126,10 +145,10 @@ def run_forward(model, x, text, t, save: bool):
     # ---- time embedding + every adaLN modulation of the network in one GEMM ----
     te = c.time_embed_dim
     tsin = E(B, d); ops.timestep_embedding(t, tsin, c.flip_sin_to_cos, float(c.freq_shift))
-    e1 = E(B, te); ops.gemm(tsin, P.t1_w, e1, P.t1_b)
-    ops.silu(e1, e1)
-    emb = E(B, te); ops.gemm(e1, P.t2_w, emb, P.t2_b)
-    ops.silu(emb, emb)                                    # every consumer applies SiLU(emb) first
+    e1_pre = E(B, te); ops.gemm(tsin, P.t1_w, e1_pre, P.t1_b)
+    e1 = E(B, te); ops.silu(e1_pre, e1)
+    emb_pre = E(B, te); ops.gemm(e1, P.t2_w, emb_pre, P.t2_b)
+    emb = E(B, te); ops.silu(emb_pre, emb)                # every consumer applies SiLU(emb) first
     mod = E(B, P.w_ada.shape[0], dt=torch.float32); ops.gemm(emb, P.w_ada, mod, P.b_ada)
 
     # ---- patch / text embedding into the joint [text, video] sequence ----
@@ -167,19 +186,25 @@ def run_forward(model, x, text, t, save: bool):
         if st is not None:
             ops.lora_down(o, st.a_out(st.flat_bf16, i), st.r, o[:, d:], d)
         h1 = E(M, d)
+        ao = E(M, d) if (save and ft is not None) else None           # branch output before gating (gate gradient)
         ops.gemm(o, Lw.w_o, h1, Lw.b_o, epilogue=EPI_GATED_RES, residual=h, gate_txt=m1.gate_txt, gate_vid=m1.gate_vid,
-                 gate_bstride=m1.bs, S=S, St=St, K=KE)
+                 gate_bstride=m1.bs, S=S, St=St, K=KE, pre_act_out=ao)
         # --- feed-forward branch ---
         a.mean2, a.rstd2 = E(M, dt=torch.float32), E(M, dt=torch.float32)
-        ops.ln_modulate_fwd(h1, xg, Lw.n2g, Lw.n2b, (m2.shift_txt, m2.scale_txt, m2.shift_vid, m2.scale_vid, m2.bs),
+        keep_ff = save and ft is not None                              # dW1 / dW2 need the FF inputs
+        x2 = E(M, d) if keep_ff else xg
+        gact = E(M, c.ff_mult * d) if keep_ff else gbuf
+        ops.ln_modulate_fwd(h1, x2, Lw.n2g, Lw.n2b, (m2.shift_txt, m2.scale_txt, m2.shift_vid, m2.scale_vid, m2.bs),
                             a.mean2, a.rstd2, d, S, St, c.norm_eps)
         u = E(M, c.ff_mult * d) if save else gbuf.new_empty(M, c.ff_mult * d)
-        ops.gemm(xg, Lw.w1, gbuf, Lw.b1, epilogue=EPI_BIAS_GELU, pre_act_out=u)
+        ops.gemm(x2, Lw.w1, gact, Lw.b1, epilogue=EPI_BIAS_GELU, pre_act_out=u)
         h2 = E(M, d)
-        ops.gemm(gbuf, Lw.w2, h2, Lw.b2, epilogue=EPI_GATED_RES, residual=h1, gate_txt=m2.gate_txt, gate_vid=m2.gate_vid,
-                 gate_bstride=m2.bs, S=S, St=St)
+        fo = E(M, d) if keep_ff else None
+        ops.gemm(gact, Lw.w2, h2, Lw.b2, epilogue=EPI_GATED_RES, residual=h1, gate_txt=m2.gate_txt, gate_vid=m2.gate_vid,
+                 gate_bstride=m2.bs, S=S, St=St, pre_act_out=fo)
         if save:
             a.x1, a.qkv, a.qkh, a.o, a.lse, a.h1, a.u = x1, qkv, qkh, o, lse, h1, u
+            a.x2, a.g, a.ao, a.fo = (x2, gact, ao, fo) if ft is not None else (None, None, None, None)
             saved.append(a)
         h = h2
 
@@ -203,6 +228,8 @@ def run_forward(model, x, text, t, save: bool):
     if save:
         ctx = SimpleNamespace(blocks=saved, mod=mod, h_last=h, y1=y1, fm1=fm1, fr1=fr1, fm2=fm2, fr2=fr2,
                               dims=(B, Fr, C, Hh, Ww, S, St, Sv, M), f_scale=f_scale)
+        if ft is not None:
+            ctx.y2, ctx.tsin, ctx.e1_pre, ctx.e1, ctx.emb_pre, ctx.se, ctx.patches, ctx.text = y2, tsin, e1_pre, e1, emb_pre, emb, patches, text
     return out, ctx
 
 
@@ -284,7 +311,11 @@ class _DiTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        run_backward(ctx.model, ctx.saved, dout.contiguous())
+        if getattr(ctx.model, "fullft", None) is not None:
+            from .engine_fullft import run_backward_fullft
+            run_backward_fullft(ctx.model, ctx.saved, dout.contiguous())
+        else:
+            run_backward(ctx.model, ctx.saved, dout.contiguous())
         ctx.saved = None
         return None, None, None, None, None
 
@@ -304,7 +335,8 @@ def dit_apply(model, hidden_states, encoder_hidden_states, timestep):
         timestep = timestep[None].expand(x.shape[0])
     t = timestep.to(torch.int64).contiguous()
     st = model.lora
-    need_grad = torch.is_grad_enabled() and st is not None and any(p.requires_grad for p in st.params)
+    need_grad = torch.is_grad_enabled() and ((st is not None and any(p.requires_grad for p in st.params))
+                                             or getattr(model, "fullft", None) is not None)
     if not need_grad:
         out, _ = run_forward(model, x, text, t, save=False)
         return out

@@ -98,6 +98,57 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     return out
 
 
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, P: Optional[int] = None, Q: Optional[int] = None,
+            alpha: float = 1.0, accumulate: bool = True):
+    """c[P,Q] (+)= alpha * a[:, :P]^T @ b[:, :Q]  (reduction over the rows; c is fp32)."""
+    _req(a, BF16, "a", 2); _req(b, BF16, "b", 2); _req(c, torch.float32, "c", 2)
+    P = a.shape[1] if P is None else P
+    Q = b.shape[1] if Q is None else Q
+    check(load_library().vt_gemm_nt_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+                                         a.shape[0], P, Q, alpha, int(accumulate), _stream()), "vt_gemm_nt_bf16")
+
+
+def group_colsum(x, out1, y=None, out2=None, mean=None, rstd=None, D: Optional[int] = None, S: int = 1, St: int = 0,
+                 grouped: bool = False, o_bstride: Optional[int] = None, o_segstride: Optional[int] = None):
+    """out1 += column sums of x; out2 += column sums of x*y (y normalised with mean/rstd when given).  grouped: the sums of
+    (sample b, seg) land at out + b*o_bstride + seg*o_segstride (defaults: a dense [2B, D] array, text row first)."""
+    _req(x, BF16, "x", 2)
+    D = x.shape[1] if D is None else D
+    ob = 2 * D if o_bstride is None else o_bstride
+    osg = D if o_segstride is None else o_segstride
+    check(load_library().vt_group_colsum(x.data_ptr(), x.stride(0), _p(y), 0 if y is None else y.stride(0), _p(mean), _p(rstd),
+                                         _p(out1), _p(out2), x.shape[0], D, S, St, int(grouped), ob, osg, _stream()),
+          "vt_group_colsum")
+
+
+def qk_ln_param_grads(dq_hat_f32, dk_hat, qkv, mean, rstd, out, H: int):
+    check(load_library().vt_qk_ln_param_grads(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
+                                              qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), out.data_ptr(),
+                                              qkv.shape[0], H, _stream()), "vt_qk_ln_param_grads")
+
+
+def ln_param_combine(G1, G2, D: int, gamma, beta, scales, dgamma, dbeta, dmods, grouped: bool):
+    """scales: None or (scale_txt, scale_vid, bstride); dmods: None or (dshift_txt, dshift_vid, dscale_txt, dscale_vid, bstride)."""
+    sc = (None, None, 0) if scales is None else scales
+    dm = (None, None, None, None, 0) if dmods is None else dmods
+    check(load_library().vt_ln_param_combine(G1.data_ptr(), G2.data_ptr(), G1.shape[0], D, _p(gamma), _p(beta), _p(sc[0]), _p(sc[1]),
+                                             sc[2], _p(dgamma), _p(dbeta), _p(dm[0]), _p(dm[1]), _p(dm[2]), _p(dm[3]), dm[4],
+                                             int(grouped), _stream()), "vt_ln_param_combine")
+
+
+def small_linear_bwd(dy_f32, x, W, dW, db, dx):
+    """dy [Bn,N] fp32, x [Bn,K] bf16, W [N,K] bf16; dW [N,K] / db [N] / dx [Bn,K] fp32 accumulated (any may be None)."""
+    Bn, N = dy_f32.shape
+    K = W.shape[1]
+    check(load_library().vt_small_linear_bwd(dy_f32.data_ptr(), dy_f32.stride(0), x.data_ptr(), x.stride(0), W.data_ptr(), _p(dW),
+                                             _p(db), _p(dx), 0 if dx is None else dx.stride(0), Bn, N, K, _stream()),
+          "vt_small_linear_bwd")
+
+
+def silu_bwd(dy_f32, x_pre, dx_f32):
+    check(load_library().vt_silu_bwd(dy_f32.data_ptr(), x_pre.data_ptr(), dx_f32.data_ptr(), dy_f32.numel(), _stream()), "vt_silu_bwd")
+
+
 def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None, q_prescaled: bool = False):
     """q,k,v,o: views whose element (b,s,h,d) is at base + b*bs + s*rs + h*64 + d; given as 3-d [B,S,>=H*64]."""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):

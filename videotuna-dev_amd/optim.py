@@ -15,18 +15,25 @@ from . import ops
 
 class FusedAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, lora_state=None):
+                 weight_decay: float = 1e-2, lora_state=None, fullft_state=None):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
-        for p in self.params:
-            if p.dtype != torch.float32:
-                raise TypeError("FusedAdamW keeps fp32 master weights; got a parameter of dtype %s" % p.dtype)
+        if fullft_state is None:
+            for p in self.params:
+                if p.dtype != torch.float32:
+                    raise TypeError("FusedAdamW keeps fp32 master weights; got a parameter of dtype %s "
+                                    "(bf16 base weights need vt355.fullft.enable_full_finetune)" % p.dtype)
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         self.param_groups = [dict(params=self.params, **self.defaults)]
-        self.lora_state = lora_state
+        self.lora_state = lora_state if lora_state is not None else fullft_state      # both expose flat / grad / flat_bf16 / version
+        self.is_fullft = fullft_state is not None
+        lora_state = self.lora_state
         self.step_count = 0
-        if lora_state is not None:
+        if self.is_fullft:
+            self.m = torch.zeros_like(fullft_state.flat)
+            self.v = torch.zeros_like(fullft_state.flat)
+        elif lora_state is not None:
             if sum(p.numel() for p in self.params) != sum(p.numel() for p in lora_state.params):
                 raise ValueError("flat mode needs exactly the adapter parameters of the LoraState")
             self.m = torch.zeros_like(lora_state.flat)

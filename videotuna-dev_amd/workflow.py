@@ -76,7 +76,12 @@ class CogVideoXWorkFlow(nn.Module):
     def configure_optimizers(self):
         params = [p for p in self.model.parameters() if p.requires_grad]
         st = getattr(self.model, "_lora_state", None)
-        return FusedAdamW(params, lr=self.learning_rate, lora_state=st)
+        ft = getattr(self.model, "fullft", None)
+        if st is None and ft is None and any(p.dtype != torch.float32 for p in params):
+            from .fullft import enable_full_finetune        # reference `-fullft` recipes: no adapter_config, all weights train
+            ft = enable_full_finetune(self.model)
+            params = ft.params
+        return FusedAdamW(params, lr=self.learning_rate, lora_state=st, fullft_state=ft)
 
     def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> Dict[str, Any]:
         sd = {k: v for k, v in checkpoint["state_dict"].items() if "lora" in k}

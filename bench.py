@@ -55,10 +55,13 @@ def main():
     ap.add_argument("--accum", type=int, default=2)
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
+                    help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
     args = ap.parse_args()
 
     from vt355 import ops
-    from vt355.ddp import FlatGradReducer, broadcast_flat, init_from_env
+    from vt355.ddp import BucketedReducer, FlatGradReducer, broadcast_flat, init_from_env
+    from vt355.fullft import enable_full_finetune
     from vt355.dit import CogVideoXTransformer3DModel
     from vt355.lora import LoraConfig, get_peft_model
     from vt355.optim import FusedAdamW
@@ -82,14 +85,20 @@ def main():
             p.normal_(0.0, 0.02, generator=gen)
             if name.endswith(("norm.weight", "norm_final.weight", "norm_q.weight", "norm_k.weight")):
                 p.add_(1.0)
-    model.requires_grad_(False)
-    peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
-    st = peft._lora_state
-    broadcast_flat(st.flat); st.mark_changed()
     lr = 6e-6 * world * args.micro_batch            # scripts/train.py:180-185  lr = world * bs * base_lr
-    opt = FusedAdamW(st.params, lr=lr, lora_state=st)
+    if args.mode == "lora":
+        model.requires_grad_(False)
+        peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
+        st = peft._lora_state
+        broadcast_flat(st.flat); st.mark_changed()
+        opt = FusedAdamW(st.params, lr=lr, lora_state=st)
+        red = FlatGradReducer(st.grad)
+    else:
+        peft = model
+        st = enable_full_finetune(model)
+        opt = FusedAdamW(st.params, lr=lr, fullft_state=st)
+        red = BucketedReducer(st.grad)
     sched = CogVideoXDPMScheduler()
-    red = FlatGradReducer(st.grad)
 
     B, Fr, C, Hh, Ww, St = args.micro_batch, 13, 16, 60, 90, 226
     dgen = torch.Generator(device=dev).manual_seed(20230211 + rank)      # per-rank data / in-step RNG
@@ -113,11 +122,18 @@ def main():
             out = peft(hidden_states=noisy, encoder_hidden_states=text, timestep=t, return_dict=False)[0]
             sa, sb, w = sched.coefficients(t)
             loss = _LossFn.apply(out, noisy, x0, sa, sb, w)
+            if args.mode == "fullft":             # DDP no_sync: slices are all-reduced only on the last micro-batch,
+                st.on_grads_ready = red.hook if mb == args.accum - 1 else None      # as the backward finishes them
             (loss / args.accum).backward()
             losses.append(loss.detach())
-        red.reduce_async()                        # one RCCL all-reduce of the flat LoRA gradient ...
+        if args.mode == "lora":
+            red.reduce_async()                    # one RCCL all-reduce of the flat LoRA gradient ...
         batches = [make_batch() for _ in range(args.accum)]   # ... overlapped with the next step's input generation
-        red.wait()
+        if args.mode == "lora":
+            red.wait()
+        else:
+            covered = red.wait_all()
+            assert covered == st.numel, (covered, st.numel)   # every gradient element was reduced exactly once
         opt.step(grad_scale=red.grad_scale)
 
     def barrier():
@@ -166,12 +182,16 @@ def main():
         except Exception:
             traffic = None
         res = {
-            "metric": "finetune samples/sec, CogVideoX-2B T2V LoRA 49x480x720 bf16", "value": samples / elapsed,
+            "metric": "finetune samples/sec, CogVideoX-2B T2V %s 49x480x720 bf16" % ("LoRA" if args.mode == "lora" else "full-FT"),
+            "value": samples / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "CogVideoX-2B T2V LoRA finetune 49x480x720 (configs[1]): latents [2,13,16,60,90], "
-                                   "text [2,226,4096], r=4 LoRA on to_q/k/v/out, accumulate_grad_batches 2",
+            "config": {"workload": ("CogVideoX-2B T2V LoRA finetune 49x480x720 (configs[1]): latents [2,13,16,60,90], "
+                                    "text [2,226,4096], r=4 LoRA on to_q/k/v/out, accumulate_grad_batches 2") if args.mode == "lora" else
+                                   ("CogVideoX-2B T2V FULL finetune 49x480x720 (configs[2]): all 1.69 B weights trainable, fp32 master "
+                                    "+ fused AdamW, per-block gradient slices all-reduced under the backward"),
+                       "mode": args.mode,
                        "micro_batch": args.micro_batch, "accumulate_grad_batches": args.accum,
                        "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": args.layers,
                        "parallelism": f"dp{world}", "recompute": "none (activations kept in HBM)",

@@ -66,3 +66,36 @@ def shard_indices(n_items: int, rank: int, world: int):
 def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+class BucketedReducer:
+    """Full fine-tuning: the flat fp32 gradient buffer (6.8 GB for CogVideoX-2B) is all-reduced in slices as the backward
+    finishes them -- one slice per transformer block, last block first, ~225 MB each -- with ``async_op=True`` so RCCL
+    runs them on its own stream while the engine keeps computing earlier blocks (the DDP bucket overlap of the reference's
+    ``DDPStrategy``, without re-bucketing copies: the slices ARE the gradient storage).  xGMI is point-to-point: a few
+    large slices keep every link busy; the 1/world mean is folded into the optimizer's ``grad_scale``.
+    Install ``reducer.hook`` as ``FullFTState.on_grads_ready`` for the LAST micro-batch of an accumulation window only
+    (``no_sync`` semantics), then ``wait_all()`` before the optimizer step."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None):
+        self.grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._works = []
+        self.covered = 0
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def hook(self, lo: int, hi: int):
+        self.covered += hi - lo
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_all(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        covered, self.covered = self.covered, 0
+        return covered

@@ -313,7 +313,7 @@ class _DiTFn(torch.autograd.Function):
     def backward(ctx, dout):
         if getattr(ctx.model, "fullft", None) is not None:
             from .engine_fullft import run_backward_fullft
-            run_backward_fullft(ctx.model, ctx.saved, dout.contiguous())
+            run_backward_fullft(ctx.model, ctx.saved, dout.contiguous(), ctx.model.fullft.on_grads_ready)
         else:
             run_backward(ctx.model, ctx.saved, dout.contiguous())
         ctx.saved = None

@@ -78,6 +78,7 @@ class FullFTState:
                 named[n].requires_grad_(True)
         self.params = [named[n] for n in order]
         self.version = 0
+        self.on_grads_ready = None      # callable(lo, hi) fired by the backward when grad[lo:hi] is final (DDP overlap)
         self.model = model
         model.fullft = self
         model._packed = None

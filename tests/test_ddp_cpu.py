@@ -45,3 +45,24 @@ def test_single_process_reducer_is_identity():
     r = FlatGradReducer(g)
     r.reduce()
     assert r.grad_scale == 1.0 and torch.all(g == 1)
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vt355.ddp import BucketedReducer, init_from_env
+    init_from_env(backend="gloo")
+    grad = torch.full((1000,), float(rank + 1))
+    red = BucketedReducer(grad)
+    # slices arrive in backward order (last block first), exactly once each
+    for lo, hi in ((800, 1000), (400, 800), (100, 400), (0, 100)):
+        red.hook(lo, hi)
+    covered = red.wait_all()
+    out[rank] = (covered, bool(torch.all(grad == 3.0)), red.grad_scale)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_bucketed_reducer_world2():
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r] == (1000, True, 0.5)

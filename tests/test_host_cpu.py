@@ -100,3 +100,58 @@ def test_hf_key_names_and_shapes():
         assert tuple(sd[k].shape) == s, k
     n = sum(int(torch.tensor(s).prod()) for s in O.param_shapes(O.DiTConfig()).values())
     assert abs(n - 1.69e9) < 0.02e9
+
+
+def test_full_finetune_flat_layout():
+    """FullFTState re-homes every parameter into one flat buffer: HF names kept, fused groups contiguous, slices cover it."""
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.fullft import enable_full_finetune
+    m = CogVideoXTransformer3DModel(num_layers=2, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64).init_weights(0)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ft = enable_full_finetune(m)
+    assert set(ft.names) == set(before) and ft.numel == sum(v.numel() for v in before.values())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k                                    # values unchanged, names unchanged
+    base = ft.flat_bf16.data_ptr()
+    for n, p in m.named_parameters():
+        off, shp = ft.offsets[n]
+        assert p.data_ptr() == base + 2 * off and off % 8 == 0 and p.requires_grad
+    d = m.inner_dim
+    w = ft.span(ft.flat_bf16, "transformer_blocks.1.attn1.to_q.weight", "transformer_blocks.1.attn1.to_v.weight", (3 * d, d))
+    assert torch.equal(w[d:2 * d], m.transformer_blocks[1].attn1.to_k.weight)
+    nmod = (12 * 2 + 2) * d
+    wa = ft.span(ft.flat_bf16, "transformer_blocks.0.norm1.linear.weight", "norm_out.linear.weight", (nmod, 64))
+    assert torch.equal(wa[6 * d:12 * d], m.transformer_blocks[0].norm2.linear.weight)
+    assert torch.equal(ft.flat, ft.flat_bf16.float())
+    with pytest.raises(RuntimeError):
+        m.to(torch.float32)
+
+
+def test_from_pretrained_reads_hf_layout(tmp_path):
+    """HF directory layout (config.json + diffusion_pytorch_model.safetensors with diffusers key names) round-trips through
+    from_pretrained / instantiate_from_config -- the loader a session WITH checkpoints/cogvideo/CogVideoX-2b would use."""
+    import json
+    from safetensors.torch import save_file
+    from vt355.config import instantiate_from_config
+    from vt355.dit import CogVideoXTransformer3DModel
+    cfg = dict(num_layers=2, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64, sample_width=8, sample_height=6,
+               sample_frames=5, max_text_seq_length=10, _class_name="CogVideoXTransformer3DModel", _diffusers_version="0.32.2")
+    src = CogVideoXTransformer3DModel(**{k: v for k, v in cfg.items() if not k.startswith("_")}).init_weights(5)
+    root = tmp_path / "CogVideoX-tiny" / "transformer"
+    root.mkdir(parents=True)
+    (root / "config.json").write_text(json.dumps(cfg))
+    sd = {k: v.contiguous() for k, v in src.state_dict().items()}
+    sd["patch_embed.pos_embedding"] = torch.zeros(1, 10 + 24, 128)       # diffusers stores the fixed table: ignored, regenerated
+    save_file(sd, str(root / "diffusion_pytorch_model.safetensors"))
+    m = instantiate_from_config({"target": "diffusers.CogVideoXTransformer3DModel",
+                                 "params": {"pretrained_model_name_or_path": str(tmp_path / "CogVideoX-tiny"),
+                                            "subfolder": "transformer", "load_dtype": "fp16"}})
+    assert isinstance(m, CogVideoXTransformer3DModel) and m.config.num_layers == 2
+    for k, v in src.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    (tmp_path / "sch").mkdir()
+    (tmp_path / "sch" / "scheduler_config.json").write_text(json.dumps({"_class_name": "CogVideoXDPMScheduler", "snr_shift_scale": 1.0,
+                                                                       "beta_start": 0.00085, "beta_end": 0.012}))
+    s = instantiate_from_config({"target": "diffusers.CogVideoXDPMScheduler",
+                                 "params": {"pretrained_model_name_or_path": str(tmp_path), "subfolder": "sch"}})
+    assert s.config.snr_shift_scale == 1.0

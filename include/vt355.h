@@ -156,8 +156,11 @@ int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long lo
 int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,
                  int zero_cols, void* stream);                   /* T[M,16] = X A^T ; T[:,16:16+zero_cols] = 0 */
 int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
-                 long long osr, float alpha, long long M, int P, void* stream);
-                                                                 /* out[p*osp+r*osr] += alpha*sum_m Big[m,p]*Small[m,r] */
+                 long long osr, float alpha, long long M, int P, float* workspace, void* stream);
+                                                                 /* out[p*osp+r*osr] += alpha*sum_m Big[m,p]*Small[m,r];
+                                                                    workspace: NULL (atomics) or vt_skinny_tn_workspace_bytes(P)
+                                                                    bytes (two-stage, reproducible, no contended atomics) */
+long long vt_skinny_tn_workspace_bytes(int P);
 int vt_lora_up_add(void* dX, int ldx, const void* dT, int ldt, const void* A, int lda, int R, long long M, int K,
                    void* stream);                                /* dX += dT A                          */
 int vt_lora_pack_b(const float* Bcat, void* Wext, int ldw, int n_adapters, int d_out, int r, float scale, void* stream);

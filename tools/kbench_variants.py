@@ -10,7 +10,7 @@ dev = torch.device("cuda:0"); BF = torch.bfloat16
 lib = load_library()
 exp = C.CDLL(os.path.join(ROOT, "videotuna-dev_amd", "libvt355_exp.so"))
 variants = {"shipped": lib.vt_attn_bwd_hd64}
-for suf in sys.argv[1:] or ["_n2", "_n3", "_abl1", "_abl2"]:
+for suf in sys.argv[1:] or ["_shift", "_abl1", "_abl2"]:
     fn = getattr(exp, "vt_attn_bwd_hd64" + suf)
     fn.argtypes = PROTOTYPES["vt_attn_bwd_hd64"]; fn.restype = C.c_int
     variants[suf] = fn

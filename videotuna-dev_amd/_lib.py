@@ -49,12 +49,13 @@ PROTOTYPES = {
     "vt_diffusion_loss_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
     "vt_adamw": [_fp, _fp, _fp, _fp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp],
     "vt_lora_down": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _i, _vp],
-    "vt_skinny_tn": [_vp, _i, _vp, _i, _i, _fp, _ll, _ll, _f, _ll, _i, _vp],
+    "vt_skinny_tn": [_vp, _i, _vp, _i, _i, _fp, _ll, _ll, _f, _ll, _i, _fp, _vp],
+    "vt_skinny_tn_workspace_bytes": [_i],
     "vt_lora_up_add": [_vp, _i, _vp, _i, _vp, _i, _i, _ll, _i, _vp],
     "vt_lora_pack_b": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
     "vt_lora_pack_bt": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
 }
-_RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p}
+_RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p, "vt_skinny_tn_workspace_bytes": C.c_longlong}
 
 
 def load_library():

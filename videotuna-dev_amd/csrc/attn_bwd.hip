@@ -31,6 +31,9 @@
 #ifndef VT_DRAIN
 #define VT_DRAIN 0    // 1 = spread each step's 16 dQ atomics over the next step's MFMA slots (measured SLOWER: 10.5 vs 8.9 ms)
 #endif
+#ifndef VT_DQSHIFT
+#define VT_DQSHIFT 0   // 1 = the dQ MFMAs of step t-1 run inside step t VALU-bound slots (measured SLOWER: 11.5 vs 8.9 ms, the atomics then leave every wave in one burst right after the barrier)
+#endif
 #ifndef VT_ABL
 #define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write
 #endif
@@ -304,6 +307,20 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
         f32x16 sA, pA, sB, pB;
         bf16x8 qa[4], doa[4], qT[2][2], doT[2][2];
         unsigned pwA[8], dwA[8], pwB[8], dwB[8];
+#if VT_DQSHIFT
+        // dQ tile of the PREVIOUS step (its dS image sits in the other buffer): 16 MFMAs that depend on nothing in this
+        // step, issued inside the two slots that have only 8 MFMAs for 8 softmax pairs (operands one k-step ahead)
+        const char* dsprev = smem + DSIMG + (buf ^ 1) * 32768;
+        f32x16 dqp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqp[i] = 0.f;
+        bf16x8 ra[2], rb[2];
+        auto dq_load = [&](int s3, int slot) {
+            ra[slot] = tr_pair(dsprev + s3 * 2048 + trQA[0], dsprev + s3 * 2048 + trQA[1]);
+            rb[slot] = tr_pair(smem + KIMG + s3 * 2048 + trQB[0], smem + KIMG + s3 * 2048 + trQB[1]);
+        };
+        dq_load(0, 0);
+#endif
         rowfrags(0, qa, doa);
         qk_init(0, 0, sA, pA);
 #pragma unroll
@@ -312,7 +329,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
         // slot 0: QK(1) || SM(0)
         qk_init(0, 1, sB, pB);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { qk_mfma(m, 1, qa, doa, sB, pB); sm_pair(m, sA, pA, pwA, dwA); if (m & 1) drain(m >> 1); }
+        for (int m = 0; m < 8; ++m) {
+            qk_mfma(m, 1, qa, doa, sB, pB);
+#if VT_DQSHIFT
+            dq_load(m + 1, (m + 1) & 1);                  // k-step 8 is loaded here for slot 3
+            dqp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[m & 1], rb[m & 1], dqp, 0, 0, 0);
+#endif
+            sm_pair(m, sA, pA, pwA, dwA);
+            if (m & 1) drain(m >> 1);
+        }
         rowfrags(1, qa, doa);
         wr_ds(0, 0, dwA);
         // slot 1: PV(0) + QK(2) || SM(1)
@@ -338,7 +363,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
         trfrags(1, qT, doT);
         // slot 3: PV(2) || SM(3)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { pv_mfma(m, 0, qT, doT, pwA, dwA); sm_pair(m, sB, pB, pwB, dwB); if (m & 1) drain(12 + (m >> 1)); }
+        for (int m = 0; m < 8; ++m) {
+            pv_mfma(m, 0, qT, doT, pwA, dwA);
+#if VT_DQSHIFT
+            if (m + 1 < 8) dq_load(8 + m + 1, (m + 1) & 1);
+            dqp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[m & 1], rb[m & 1], dqp, 0, 0, 0);
+#endif
+            sm_pair(m, sB, pB, pwB, dwB);
+            if (m & 1) drain(12 + (m >> 1));
+        }
         wr_ds(1, 1, dwB);
         // PV(3): exposed
 #pragma unroll
@@ -416,6 +449,22 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
         __syncthreads();
 
 #if VT_ABL != 1
+#if VT_PIPE && VT_DQSHIFT
+        // ---- atomics of the dQ tile that was accumulated during this step (it belongs to step t-1) ----
+        if (t > 0)
+        {
+            const int soff = (int)((long long)(t - 1) * 64 * p.dq_rs * 4);
+#if VT_ABL == 2
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dqp[i]));
+#else
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dqp[i] * p.scale, rdq,
+                                                                dq_voff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, soff, 0);
+#endif
+        }
+#else
         // ---- dQ tile (32 q x 32 d) of this wave over all 256 keys ----
         f32x16 dq_acc;
 #pragma unroll
@@ -438,16 +487,8 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
                 dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s3 % 3], fb[s3 % 3], dq_acc, 0, 0, 0);
             }
         }
-#if VT_PIPE && VT_DRAIN
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dq_prev[i] = dq_acc[i] * p.scale;
-#if VT_ABL == 2
-#pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_prev[i]));
-#endif
-#else
         {
-            const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
+            const int soff = (int)((long long)(t) * 64 * p.dq_rs * 4);
 #if VT_ABL == 2
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
@@ -462,12 +503,42 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
 #endif
     }
 
-#if VT_PIPE && VT_DRAIN && VT_ABL != 1 && VT_ABL != 2
-    {
-        const int soff_last = (int)((long long)(nsteps - 1) * 64 * p.dq_rs * 4);
+#if VT_PIPE && VT_DQSHIFT && VT_ABL != 1
+    {   // the last step's dQ tile: nobody computes it "one step later"
+        const char* dslast = smem + DSIMG + ((nsteps - 1) & 1) * 32768;
+        f32x16 dq_acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_prev[i], rdq, dq_voff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, soff_last, 0);
+        for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
+        {
+            // operands are fetched two k-steps ahead of the MFMA that consumes them (one wave per SIMD: nothing else
+            // hides the LDS latency)
+            bf16x8 fa[3], fb[3];
+#pragma unroll
+            for (int s3 = 0; s3 < 2; ++s3) {
+                fa[s3] = tr_pair(dslast + s3 * 2048 + trQA[0], dslast + s3 * 2048 + trQA[1]);
+                fb[s3] = tr_pair(smem + KIMG + s3 * 2048 + trQB[0], smem + KIMG + s3 * 2048 + trQB[1]);
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 16; ++s3) {
+                if (s3 + 2 < 16) {
+                    fa[(s3 + 2) % 3] = tr_pair(dslast + (s3 + 2) * 2048 + trQA[0], dslast + (s3 + 2) * 2048 + trQA[1]);
+                    fb[(s3 + 2) % 3] = tr_pair(smem + KIMG + (s3 + 2) * 2048 + trQB[0], smem + KIMG + (s3 + 2) * 2048 + trQB[1]);
+                }
+                dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s3 % 3], fb[s3 % 3], dq_acc, 0, 0, 0);
+            }
+        }
+        {
+            const int soff = (int)((long long)(nsteps - 1) * 64 * p.dq_rs * 4);
+#if VT_ABL == 2
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
+#else
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq,
+                                                                dq_voff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, soff, 0);
+#endif
+        }
     }
 #endif
     // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----

@@ -52,22 +52,23 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 
-// ---------------- out[p*osp + r*osr] += alpha * sum_m Big[m,p] * Small[m,r]   (fp32 atomics) ----------------
-// The output is tiny (P x R) and every block adds into all of it, so the cost is the CONTENDED atomics, not the
-// streaming: M is cut into only SK_SLICES row slices (one atomic per output element per slice), columns into 512-wide
-// blocks of 128 threads (4 columns = one 8-byte load per thread and row), and the rows of a slice are walked 16 at a
-// time with all 16 loads in flight.  The slice's Small rows are staged once in LDS as fp32.
-#define SK_SLICES 64
-#define SK_MAXROWS 512         // rows per slice that fit the LDS staging (32768 rows per launch chunk)
+// ---------------- out[p*osp + r*osr] += alpha * sum_m Big[m,p] * Small[m,r] ----------------
+// The output is tiny (P x R) while M is long, so the reduction is split over SK_SLICES row slices.  Contended fp32
+// atomics into such a small target run at ~0.1 TB/s (MI355X_MICROARCH.md, global float atomics), so when the caller
+// provides a workspace the slices write their partial [P, RR] tiles with plain stores and a second tiny kernel sums
+// them in a fixed order (also bitwise reproducible); without a workspace the partials are added with atomics.
+// Columns: 512-wide blocks of 128 threads (4 columns = one 8-byte load per thread and row), rows of a slice walked 16 at
+// a time with all 16 loads in flight; the slice's Small rows are staged once in LDS as fp32.
+#define SK_SLICES 128
+#define SK_MAXROWS 512         // rows per slice that fit the LDS staging
 template <int RR>
 __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
                                                        float* out, long long osp, long long osr, float alpha,
-                                                       long long M, int P, int rows_per_slice) {
+                                                       long long M, int P, int rows_per_slice, float* ws) {
     __shared__ __attribute__((aligned(16))) float sm[SK_MAXROWS * RR];
     const long long m0 = (long long)blockIdx.y * rows_per_slice;
-    if (m0 >= M) return;
-    const int rows = (int)((M - m0) < rows_per_slice ? (M - m0) : rows_per_slice);
     const int p = (blockIdx.x * 128 + threadIdx.x) * 4;
+    const int rows = m0 < M ? (int)((M - m0) < rows_per_slice ? (M - m0) : rows_per_slice) : 0;
     for (int i = threadIdx.x; i < rows * RR; i += 128) {
         const int mm = i / RR, rr = i - mm * RR;
         sm[i] = rr < R ? bf2f(Small[(size_t)(m0 + mm) * lds_ + rr]) : 0.f;
@@ -112,16 +113,39 @@ __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int l
             acc[0][rr] += b0 * sv; acc[1][rr] += b1 * sv; acc[2][rr] += b2 * sv; acc[3][rr] += b3 * sv;
         }
     }
+    if (ws != nullptr) {
+        // partial tile of this slice: ws[slice][p][RR]  (16-byte stores, 4 rows of RR floats per thread)
+        float* w = ws + ((size_t)blockIdx.y * P + p) * RR;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int rr = 0; rr < RR; ++rr)
-            if (rr < R) atomicAdd(out + (size_t)(p + c) * osp + (size_t)rr * osr, alpha * acc[c][rr]);
+            for (int r4 = 0; r4 < RR / 4; ++r4)
+                *(f32x4*)(w + c * RR + 4 * r4) = (f32x4){acc[c][4 * r4], acc[c][4 * r4 + 1], acc[c][4 * r4 + 2], acc[c][4 * r4 + 3]};
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr)
+                if (rr < R) atomicAdd(out + (size_t)(p + c) * osp + (size_t)rr * osr, alpha * acc[c][rr]);
+    }
 }
+template <int RR>
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* ws, int nslices, float* out, long long osp, long long osr,
+                                                           float alpha, int P, int R) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // one (p, rr) pair per thread
+    if (i >= P * RR) return;
+    const int p = i / RR, rr = i - p * RR;
+    if (rr >= R) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += ws[(size_t)k * P * RR + i];
+    out[(size_t)p * osp + (size_t)rr * osr] += alpha * s;
+}
+extern "C" long long vt_skinny_tn_workspace_bytes(int P) { return (long long)SK_SLICES * P * 16 * 4; }
 extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
-                            long long osr, float alpha, long long M, int P, void* stream) {
+                            long long osr, float alpha, long long M, int P, float* workspace, void* stream) {
     if (M <= 0 || P <= 0 || (P % 4) || R <= 0 || R > 16 || (ldb % 4)) return VT_ERR_BAD_SHAPE;
     if (((uintptr_t)Big) & 7) return VT_ERR_BAD_ALIGN;
+    if (workspace != nullptr && (((uintptr_t)workspace) & 15)) return VT_ERR_BAD_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const long long chunk = (long long)SK_SLICES * SK_MAXROWS;          // rows handled per launch
     for (long long mbase = 0; mbase < M; mbase += chunk) {
@@ -130,10 +154,13 @@ extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds
         dim3 grid((P + 511) / 512, SK_SLICES);
         const bf16_t* bg = (const bf16_t*)Big + (size_t)mbase * ldb;
         const bf16_t* smp = (const bf16_t*)Small + (size_t)mbase * lds_;
-        if (R <= 4)
-            hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps);
-        else
-            hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps);
+        if (R <= 4) {
+            hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps, workspace);
+            if (workspace) hipLaunchKernelGGL(skinny_reduce_kernel<4>, dim3((P * 4 + 255) / 256), dim3(256), 0, st, workspace, SK_SLICES, out, osp, osr, alpha, P, R);
+        } else {
+            hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps, workspace);
+            if (workspace) hipLaunchKernelGGL(skinny_reduce_kernel<16>, dim3((P * 16 + 255) / 256), dim3(256), 0, st, workspace, SK_SLICES, out, osp, osr, alpha, P, R);
+        }
     }
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -289,10 +289,22 @@ def lora_down(x, a, R: int, t_out, K: int, zero_cols: int = 48):
                                       t_out.stride(0), x.shape[0], K, zero_cols, _stream()), "vt_lora_down")
 
 
-def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int):
+_SKINNY_WS = {}
+
+
+def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int, use_workspace: bool = True):
+    """out[p*osp + r*osr] += alpha * sum_m big[m,p] * small[m,r]; two-stage (workspace) by default: no contended atomics."""
     _req(big, BF16, "big", 2); _req(small, BF16, "small", 2); _req(out, torch.float32, "out")
-    check(load_library().vt_skinny_tn(big.data_ptr(), big.stride(0), small.data_ptr(), small.stride(0), R, out.data_ptr(),
-                                      osp, osr, alpha, big.shape[0], P, _stream()), "vt_skinny_tn")
+    lib = load_library()
+    ws = None
+    if use_workspace:
+        need = lib.vt_skinny_tn_workspace_bytes(P) // 4
+        key = big.device
+        if key not in _SKINNY_WS or _SKINNY_WS[key].numel() < need:
+            _SKINNY_WS[key] = torch.empty(need, dtype=torch.float32, device=big.device)     # reused across calls (stream-ordered)
+        ws = _SKINNY_WS[key]
+    check(lib.vt_skinny_tn(big.data_ptr(), big.stride(0), small.data_ptr(), small.stride(0), R, out.data_ptr(),
+                           osp, osr, alpha, big.shape[0], P, _p(ws), _stream()), "vt_skinny_tn")
 
 
 def lora_up_add(dx, dt, a, R: int, K: int):

@@ -63,6 +63,9 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime of this process BEFORE libvt355.so is mapped,
+    # otherwise the kernels register with a second runtime and every launch on a torch stream fails.
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise VtError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -292,8 +292,8 @@ def lora_down(x, a, R: int, t_out, K: int, zero_cols: int = 48):
 _SKINNY_WS = {}
 
 
-def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int, use_workspace: bool = True):
-    """out[p*osp + r*osr] += alpha * sum_m big[m,p] * small[m,r]; two-stage (workspace) by default: no contended atomics."""
+def skinny_tn(big, small, R: int, out, osp: int, osr: int, alpha: float, P: int, use_workspace: bool = False):
+    """out[p*osp + r*osr] += alpha * sum_m big[m,p] * small[m,r]; fp32 atomics by default; use_workspace=True selects the two-stage, bitwise-reproducible reduction (measured slightly slower)."""
     _req(big, BF16, "big", 2); _req(small, BF16, "small", 2); _req(out, torch.float32, "out")
     lib = load_library()
     ws = None

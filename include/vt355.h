@@ -64,7 +64,8 @@ int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, const float*
 
 /* dgamma/dbeta [2][2][64] (q: gamma,beta; k: gamma,beta) of the per-head LayerNorm, accumulated */
 int vt_qk_ln_param_grads(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
-                         const float* mean, const float* rstd, float* out_2x2x64, long long M, int H, void* stream);
+                         const float* mean, const float* rstd, float* out_2x2x64, long long M, int H,
+                         const float* rope_cos, const float* rope_sin, int S, int St, void* stream);
 /* LayerNorm / adaLN parameter gradients from grouped sums G1 = sum dy, G2 = sum dy*xhat (see csrc/reduce.hip) */
 int vt_ln_param_combine(const float* G1, const float* G2, int G, int D, const void* gamma, const void* beta,
                         const float* scale_txt, const float* scale_vid, int bstride, float* dgamma, float* dbeta,
@@ -113,13 +114,20 @@ int vt_ln_modulate_bwd(const void* dy, int lddy, const void* x, int ldx, const f
                        int M, int D, int S, int St, void* stream);
 
 /* per-head LayerNorm(64, affine) of the q and k thirds of a fused [M, 3*H*64] projection; writes
- * [M, 2*H*64] (q_hat | k_hat) and the statistics [M, 2H].  Replaces attn.norm_q / attn.norm_k. */
+ * [M, 2*H*64] (q_hat | k_hat) and the statistics [M, 2H].  Replaces attn.norm_q / attn.norm_k.
+ * rope_cos/rope_sin (fp32 [S-St, 64], or both NULL): rotary position embedding of the video rows (row m is sequence
+ * position m % S; positions >= St rotate), i.e. diffusers' apply_rotary_emb(use_real=True, unbind_dim=-1) that
+ * CogVideoXAttnProcessor2_0 runs on q[:, :, text_len:] / k[:, :, text_len:] with the image_rotary_emb tables built at
+ * cogvideo_pl.py:442-473 (CogVideoX-5B recipes).  The backward entry points apply the transposed rotation to the
+ * incoming gradients before the LayerNorm backward / parameter-gradient sums. */
 int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, const void* gq, const void* bq,
                         const void* gk, const void* bk, float* mean, float* rstd,
-                        long long M, int H, float eps, float q_scale, void* stream);
+                        long long M, int H, float eps, float q_scale,
+                        const float* rope_cos, const float* rope_sin, int S, int St, void* stream);
 int vt_qk_layernorm_bwd(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
                         const float* mean, const float* rstd, const void* gq, const void* gk,
-                        void* dqkv, int ldd, long long M, int H, void* stream);
+                        void* dqkv, int ldd, long long M, int H,
+                        const float* rope_cos, const float* rope_sin, int S, int St, void* stream);
 
 /* y[m,:] = x[m,:] * gate[b(m), seg(m)]  (backward of the gated residual) */
 int vt_gate_mul(const void* x, int ldx, void* y, int ldy, const float* g_txt, const float* g_vid, int bstride,

@@ -75,6 +75,7 @@ class DiTConfig:
     flip_sin_to_cos: bool = True
     freq_shift: int = 0
     use_rotary_positional_embeddings: bool = False
+    use_learned_positional_embeddings: bool = False
     ff_mult: int = 4
 
     @property
@@ -122,6 +123,57 @@ def sincos_pos_embed_3d(embed_dim: int, grid_h: int, grid_w: int, t_size: int,
     tt = np.repeat(tt[:, None, :], grid_h * grid_w, axis=1)
     sp = np.repeat(sp[None, :, :], t_size, axis=0)
     return np.concatenate([tt, sp], axis=-1)
+
+
+def resize_crop_region_for_grid(src: Tuple[int, int], target: Tuple[int, int]):
+    """Centered crop region of `src` (h, w) resized into `target` (h, w) keeping the aspect ratio
+    (videotuna/utils/common_utils.py:28-49; pinned by tests/golden/crop_region.npz)."""
+    h, w = src
+    th, tw = target
+    if h / w > th / tw:
+        rh, rw = th, int(round(th / h * w))
+    else:
+        rw, rh = tw, int(round(tw / w * h))
+    top, left = int(round((th - rh) / 2.0)), int(round((tw - rw) / 2.0))
+    return (top, left), (top + rh, left + rw)
+
+
+def rope_3d_tables(head_dim: int, crops_coords, grid_size: Tuple[int, int], temporal_size: int, theta: float = 10000.0):
+    """(cos, sin) fp32 [T*H*W, head_dim] of the 3D rotary embedding that cogvideo_pl.py:442-473 requests from diffusers'
+    get_3d_rotary_pos_embed (diffusers is not in the reference tree: restated from its published algorithm, v0.30-0.32
+    'linspace' grid).  head_dim splits t:h:w = 1/4 : 3/8 : 3/8; every frequency is repeated for its (2i, 2i+1) pair;
+    the h/w positions are linspace(start, stop, n, endpoint=False) over the crop region, the frame positions 0..T-1.
+    With the base 30x45 grid (480x720) the crop is the whole grid and positions are 0..n-1, which is exactly the in-tree
+    SAT construction dit_video_concat.py:263-320 -- tests/golden/rope_3d.npz pins that case."""
+    (top, left), (bottom, right) = crops_coords
+    gh, gw = grid_size
+    pos_h = np.linspace(top, bottom, gh, endpoint=False, dtype=np.float32)
+    pos_w = np.linspace(left, right, gw, endpoint=False, dtype=np.float32)
+    pos_t = np.arange(temporal_size, dtype=np.float32)
+    dim_t, dim_h, dim_w = head_dim // 4, head_dim // 8 * 3, head_dim // 8 * 3
+
+    def one_d(dim, pos):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        ang = torch.outer(torch.from_numpy(pos), freqs)                       # fp32, like the reference
+        return ang.cos().repeat_interleave(2, dim=1), ang.sin().repeat_interleave(2, dim=1)
+
+    (ct, st), (ch, sh), (cw, sw) = one_d(dim_t, pos_t), one_d(dim_h, pos_h), one_d(dim_w, pos_w)
+
+    def combine(a, b, c):
+        a = a[:, None, None, :].expand(-1, gh, gw, -1)
+        b = b[None, :, None, :].expand(temporal_size, -1, gw, -1)
+        c = c[None, None, :, :].expand(temporal_size, gh, -1, -1)
+        return torch.cat([a, b, c], dim=-1).reshape(temporal_size * gh * gw, -1).contiguous()
+
+    return combine(ct, ch, cw), combine(st, sh, sw)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x [..., S, hd] * cos + rotate_pairs(x) * sin with rotate_pairs(x)[2i] = -x[2i+1], [2i+1] = x[2i]
+    (dit_video_concat.py:256-260, 329-341 == diffusers apply_rotary_emb(use_real=True, unbind_dim=-1))."""
+    xr = x.reshape(*x.shape[:-1], -1, 2)
+    rot = torch.stack((-xr[..., 1], xr[..., 0]), dim=-1).reshape(x.shape)
+    return x * cos.to(x.dtype) + rot * sin.to(x.dtype)
 
 
 def joint_pos_embedding(cfg: DiTConfig, frames: int, height: int, width: int) -> torch.Tensor:
@@ -250,7 +302,7 @@ def gelu_tanh(x):
     return F.gelu(x, approximate="tanh")
 
 
-def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scale=0.25, taps=None):
+def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scale=0.25, taps=None, rope=None):
     """One CogVideoXBlock.  h_txt [B,St,D], h_vid [B,Sv,D], emb [B,te]."""
     d, H, hd = cfg.inner_dim, cfg.num_attention_heads, cfg.attention_head_dim
     St = h_txt.shape[1]
@@ -272,6 +324,9 @@ def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scal
     v = _lin(x, P, a + "to_v", lora, lora_scale).view(B, -1, H, hd).transpose(1, 2)
     q = F.layer_norm(q, (hd,), P[a + "norm_q.weight"], P[a + "norm_q.bias"], cfg.qk_norm_eps)
     k = F.layer_norm(k, (hd,), P[a + "norm_k.weight"], P[a + "norm_k.bias"], cfg.qk_norm_eps)
+    if rope is not None:                    # 5B: rotate the video positions of q and k, after the qk-LayerNorm
+        q = torch.cat([q[:, :, :St], apply_rope(q[:, :, St:], *rope)], dim=2)
+        k = torch.cat([k[:, :, :St], apply_rope(k[:, :, St:], *rope)], dim=2)
     o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
     o = o.transpose(1, 2).reshape(B, -1, d)
     if taps is not None:
@@ -293,7 +348,7 @@ def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scal
 def dit_forward(P: Dict[str, torch.Tensor], cfg: DiTConfig, hidden_states: torch.Tensor,
                 encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
                 lora: Optional[Dict[str, torch.Tensor]] = None, lora_scale: float = 0.25,
-                taps: Optional[dict] = None) -> torch.Tensor:
+                taps: Optional[dict] = None, image_rotary_emb=None) -> torch.Tensor:
     """hidden_states [B,F,C,H,W], encoder_hidden_states [B,St,text_dim], timestep int64 [B]
     -> [B,F,C,H,W] (v-prediction)."""
     dt = hidden_states.dtype
@@ -309,16 +364,24 @@ def dit_forward(P: Dict[str, torch.Tensor], cfg: DiTConfig, hidden_states: torch
     x = x.view(B, Fr, d, -1).transpose(2, 3).flatten(1, 2)           # [B, F*h*w, d], token order (t h w)
     txt = F.linear(encoder_hidden_states, P["patch_embed.text_proj.weight"], P["patch_embed.text_proj.bias"])
     St = txt.shape[1]
-    if not cfg.use_rotary_positional_embeddings:
+    if cfg.use_learned_positional_embeddings:
+        # 5B-I2V: a persistent buffer [1, max_text + patches, d] (sincos-initialised) added to the joint sequence
+        pe = P["patch_embed.pos_embedding"].to(dt)
+        txt = txt + pe[:, :St]
+        x = x + pe[:, cfg.max_text_seq_length:]
+    elif not cfg.use_rotary_positional_embeddings:
         pos = joint_pos_embedding(cfg, Fr, Hh, Ww).to(dt)
         # text slots of the table are zero; only the first St text tokens are present
         x = x + pos[cfg.max_text_seq_length:][None]
+    if cfg.use_rotary_positional_embeddings and image_rotary_emb is None:
+        raise ValueError("a RoPE config needs image_rotary_emb=(cos, sin)")
     h_txt, h_vid = txt, x
     if taps is not None:
         taps["embed_txt"], taps["embed_vid"], taps["emb"] = h_txt, h_vid, emb
     # 3. blocks
     for i in range(cfg.num_layers):
-        h_txt, h_vid = dit_block(h_txt, h_vid, emb, P, f"transformer_blocks.{i}.", cfg, lora, lora_scale, taps)
+        h_txt, h_vid = dit_block(h_txt, h_vid, emb, P, f"transformer_blocks.{i}.", cfg, lora, lora_scale, taps,
+                                 rope=image_rotary_emb)
         if taps is not None:
             taps[f"block{i}_txt"], taps[f"block{i}_vid"] = h_txt, h_vid
     # 4. final: LN (video tokens only for 2B) -> AdaLayerNorm(shift, scale) -> proj
@@ -354,10 +417,10 @@ def get_velocity(sample, noise, t, abar):
     return sa * noise - sb * sample
 
 
-def training_loss(P, cfg, x0, text, noise, t, abar, lora=None, lora_scale=0.25, taps=None):
+def training_loss(P, cfg, x0, text, noise, t, abar, lora=None, lora_scale=0.25, taps=None, image_rotary_emb=None):
     """x0 [B,F,C,H,W] latents (already scaled), text [B,St,4096], noise like x0, t int64 [B]."""
     noisy = add_noise(x0, noise, t, abar)
-    model_out = dit_forward(P, cfg, noisy, text, t, lora, lora_scale, taps)
+    model_out = dit_forward(P, cfg, noisy, text, t, lora, lora_scale, taps, image_rotary_emb=image_rotary_emb)
     pred = get_velocity(model_out, noisy, t, abar)
     w = (1.0 / (1.0 - abar[t])).to(x0.dtype).view(-1, 1, 1, 1, 1)
     B = x0.shape[0]

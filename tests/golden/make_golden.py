@@ -126,6 +126,30 @@ def main():
     np.savez(os.path.join(OUT, "modulate_unpatchify.npz"), x=x.numpy(), shift=sh.numpy(), scale=sc.numpy(),
              modulated=mod.numpy(), tokens=tok.numpy(), unpatchified=unp.numpy())
 
+    # ---------------- 2b. 3D rotary tables + rotation (CogVideoX-5B; SAT Rotary3DPositionEmbeddingMixin) ----------------
+    # The HF workflow (cogvideo_pl.py:442-473) takes its tables from diffusers' get_3d_rotary_pos_embed, which is not
+    # in the reference tree; the SAT twin dit_video_concat.py:263-341 holds the same construction in-tree
+    # (t:h:w = 16:24:24 of the 64-wide head, repeat-interleaved frequencies, rotate_half on (2i, 2i+1) pairs).
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the mixin moves its tables to a GPU in __init__; keep them here
+    try:
+        rp_small = dvc.Rotary3DPositionEmbeddingMixin(4, 5, 3, 128, 64, text_length=6)
+        rp_full = dvc.Rotary3DPositionEmbeddingMixin(30, 45, 13, 3072, 64, text_length=226)
+    finally:
+        torch.Tensor.cuda = _cuda
+    tq = torch.randn(2, 2, 3 * 4 * 5, 64)
+    rot = rp_small.rotary(tq, rope_T=3, rope_H=4, rope_W=5)
+    fc, fs = rp_full.freqs_cos.reshape(-1, 64), rp_full.freqs_sin.reshape(-1, 64)
+    np.savez(os.path.join(OUT, "rope_3d.npz"), small_cos=rp_small.freqs_cos.reshape(-1, 64).numpy(),
+             small_sin=rp_small.freqs_sin.reshape(-1, 64).numpy(), x=tq.numpy(), rotated=rot.numpy(),
+             full_rows_idx=rows, full_cos_rows=fc[rows].numpy(), full_sin_rows=fs[rows].numpy(),
+             full_cos_colsum=fc.double().sum(0).numpy(), full_sin_colsum=fs.double().sum(0).numpy())
+    cu = load_file("ref_common_utils", os.path.join(REF, "videotuna", "utils", "common_utils.py"))
+    cases = [((30, 45), (30, 45)), ((60, 90), (30, 45)), ((32, 32), (30, 45)), ((48, 30), (30, 45)), ((17, 45), (30, 45))]
+    np.savez(os.path.join(OUT, "crop_region.npz"), src=np.array([c[0] for c in cases]), tgt=np.array([c[1] for c in cases]),
+             region=np.array([cu.get_resize_crop_region_for_grid(*c) for c in cases]))
+    print("rope: ok")
+
     # ---------------- 3. CogVideoX noise schedule ----------------
     disc = load_file("sgm.modules.diffusionmodules.discretizer",
                      os.path.join(sat_dir, "sgm/modules/diffusionmodules/discretizer.py"),

@@ -3,6 +3,7 @@ LoRA key naming, checkpoint filter, product path refuses to run without the devi
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,52 @@ def test_from_pretrained_reads_hf_layout(tmp_path):
     s = instantiate_from_config({"target": "diffusers.CogVideoXDPMScheduler",
                                  "params": {"pretrained_model_name_or_path": str(tmp_path), "subfolder": "sch"}})
     assert s.config.snr_shift_scale == 1.0
+
+
+def test_cogvideox_5b_rope_host_side(tmp_path):
+    """CogVideoX-5B / 5B-I2V recipes (configs/004_cogvideox/cogvideo5b*.yaml): the workflow's rotary tables
+    (cogvideo_pl.py:442-473) against the golden vectors of the reference's in-tree construction, the I2V target remap,
+    and the learned-table buffer of the I2V transformer surviving a checkpoint round trip."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from vt355.config import get_obj_from_str
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.rope import get_3d_rotary_pos_embed, get_resize_crop_region_for_grid, prepare_rotary_positional_embeddings
+    from vt355.workflow import CogVideoXI2V, CogVideoXWorkFlow
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "rope_3d.npz"))
+    cos, sin = get_3d_rotary_pos_embed(64, ((0, 0), (4, 5)), (4, 5), 3)
+    assert np.abs(cos.numpy() - gold["small_cos"]).max() < 1e-6 and np.abs(sin.numpy() - gold["small_sin"]).max() < 1e-6
+    cos, sin = prepare_rotary_positional_embeddings(480, 720, 13)          # 49x480x720 -> 13 x 30 x 45 tokens
+    assert cos.shape == (17550, 64) and cos.dtype == torch.float32
+    idx = gold["full_rows_idx"]
+    assert np.abs(cos[idx].numpy() - gold["full_cos_rows"]).max() < 5e-6
+    assert np.abs(sin[idx].numpy() - gold["full_sin_rows"]).max() < 5e-6
+    crops = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop_region.npz"))
+    for src, tgt, reg in zip(crops["src"], crops["tgt"], crops["region"]):
+        assert np.array_equal(np.array(get_resize_crop_region_for_grid(tuple(map(int, src)), tuple(map(int, tgt)))), reg)
+    assert get_obj_from_str("videotuna.models.cogvideo_hf.cogvideo_i2v.CogVideoXI2V") is CogVideoXI2V
+    assert issubclass(CogVideoXI2V, CogVideoXWorkFlow)
+    # 5B-I2V transformer layout: rotary q/k, learned table kept as a persistent buffer, 32 input / 16 output channels
+    cfg = dict(num_layers=1, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64, sample_width=8, sample_height=6,
+               sample_frames=5, max_text_seq_length=10, in_channels=32, out_channels=16,
+               use_rotary_positional_embeddings=True, use_learned_positional_embeddings=True)
+    m = CogVideoXTransformer3DModel(**cfg).init_weights(3)
+    sd = m.state_dict()
+    assert sd["patch_embed.pos_embedding"].shape == (1, 10 + 2 * 3 * 4, 128)
+    assert "patch_embed.pos_embedding" not in dict(m.named_parameters())        # never trained
+    assert sd["patch_embed.proj.weight"].shape == (128, 32, 2, 2) and sd["proj_out.weight"].shape == (64, 128)
+    with pytest.raises(ValueError):                       # RoPE model called without tables (and vice versa): loud
+        m(hidden_states=torch.zeros(1, 2, 32, 6, 8, dtype=torch.bfloat16), encoder_hidden_states=torch.zeros(1, 10, 64),
+          timestep=torch.zeros(1, dtype=torch.long))
+    root = tmp_path / "CogVideoX-5b-I2V" / "transformer"
+    root.mkdir(parents=True)
+    (root / "config.json").write_text(json.dumps(cfg))
+    table = torch.randn(sd["patch_embed.pos_embedding"].shape).to(torch.bfloat16)
+    sd = {k: v.contiguous() for k, v in sd.items()}
+    sd["patch_embed.pos_embedding"] = table
+    save_file(sd, str(root / "diffusion_pytorch_model.safetensors"))
+    m2 = CogVideoXTransformer3DModel.from_pretrained(str(tmp_path / "CogVideoX-5b-I2V"), subfolder="transformer")
+    assert torch.equal(m2.patch_embed.pos_embedding, table)
+    with pytest.raises(ValueError):
+        CogVideoXTransformer3DModel(use_learned_positional_embeddings=True, num_layers=1)

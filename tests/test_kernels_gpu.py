@@ -205,6 +205,56 @@ def test_qk_layernorm(dev):
     close(out[:, :D], qh * SC2, 1e-2, 5e-3, "q_hat prescaled"); close(out[:, D:], kh, 1e-2, 2e-2, "k_hat untouched")
 
 
+def test_qk_layernorm_rope(dev):
+    """qk-LayerNorm with the fused rotary embedding (CogVideoX-5B): forward, input gradient and gamma/beta gradients
+    against the oracle's apply_rope on a 2-sample [text 5 | video 3x4x5] sequence; golden small tables
+    (tests/golden/rope_3d.npz, the reference's SAT mixin) drive the rotation."""
+    import os
+    import cogvideox_oracle as O
+    from vt355 import ops
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "rope_3d.npz"))
+    cos, sin = torch.from_numpy(gold["small_cos"]), torch.from_numpy(gold["small_sin"])     # [60, 64]
+    g = torch.Generator().manual_seed(12)
+    B, St, Sv, H = 2, 5, 60, 2
+    S, D = St + Sv, H * 64
+    M = B * S
+    qkv = rb(torch.randn(M, 3 * D, generator=g) * 1.5)
+    gq, bq, gk, bk = [rb(t) for t in (1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g),
+                                       1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g))]
+    x = qkv.clone().double().requires_grad_(True)
+    prm = [t.clone().double().requires_grad_(True) for t in (gq, bq, gk, bk)]
+
+    def ref(xs, ga, be):
+        y = F.layer_norm(xs.reshape(B, S, H, 64).transpose(1, 2), (64,), ga, be, 1e-6)      # [B,H,S,64]
+        y = torch.cat([y[:, :, :St], O.apply_rope(y[:, :, St:], cos.double(), sin.double())], dim=2)
+        return y.transpose(1, 2).reshape(M, D)
+    qh, kh = ref(x[:, :D], prm[0], prm[1]), ref(x[:, D:2 * D], prm[2], prm[3])
+    dqh = torch.randn(M, D, generator=g); dkh = rb(torch.randn(M, D, generator=g))
+    (qh * dqh.double()).sum().add((kh * dkh.double()).sum()).backward()
+    Q = qkv.to(dev, BF); out = torch.empty(M, 2 * D, dtype=BF, device=dev)
+    mean = torch.empty(M, 2 * H, device=dev); rstd = torch.empty(M, 2 * H, device=dev)
+    dv = [t.to(dev, BF) for t in (gq, bq, gk, bk)]
+    rope = (cos.to(dev).contiguous(), sin.to(dev).contiguous(), S, St)
+    ops.qk_layernorm_fwd(Q, out, dv[0], dv[1], dv[2], dv[3], mean, rstd, H, 1e-6, rope=rope)
+    close(out[:, :D], qh.float(), 1e-2, 2e-2, "rope q_hat"); close(out[:, D:], kh.float(), 1e-2, 2e-2, "rope k_hat")
+    # text rows are untouched by the rotation: identical bits to the rope-free kernel
+    out0 = torch.empty_like(out)
+    ops.qk_layernorm_fwd(Q, out0, dv[0], dv[1], dv[2], dv[3], mean, rstd, H, 1e-6)
+    o3, o03 = out.view(B, S, 2 * D), out0.view(B, S, 2 * D)
+    assert torch.equal(o3[:, :St], o03[:, :St]) and not torch.equal(o3[:, St:], o03[:, St:])
+    dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
+    ops.qk_layernorm_bwd(dqh.to(dev), dkh.to(dev, BF), Q, mean, rstd, dv[0], dv[2], dqkv, H, rope=rope)
+    close(dqkv[:, :2 * D], x.grad[:, :2 * D].float(), 2e-2, 2e-2, "rope qk-LN bwd")
+    pg = torch.zeros(2, 2, 64, device=dev)
+    ops.qk_ln_param_grads(dqh.to(dev), dkh.to(dev, BF), Q, mean, rstd, pg, H, rope=rope)
+    for w in range(2):
+        for gb in range(2):
+            close(pg[w, gb], prm[2 * w + gb].grad.float(), 2e-2, 2e-2, f"rope qk-LN param grad {w}{gb}")
+    # a bad table shape is refused on the host
+    with pytest.raises(ValueError):
+        ops.qk_layernorm_fwd(Q, out, dv[0], dv[1], dv[2], dv[3], mean, rstd, H, 1e-6, rope=(rope[0][:-1], rope[1][:-1], S, St))
+
+
 # ------------------------------------------------------------------ elementwise
 def test_timestep_embedding_golden(dev):
     from vt355 import ops

@@ -6,9 +6,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_tiny_train_step_matches_oracle(dev):
+@pytest.mark.parametrize("rope", [False, True], ids=["2b_sincos", "5b_rope"])
+def test_tiny_train_step_matches_oracle(dev, rope):
     from vt355.selfcheck import tiny_train_step_check
-    r = tiny_train_step_check(verbose=True, B=2)
+    r = tiny_train_step_check(verbose=True, B=2, rope=rope)
     assert r["cos"] > 0.995
 
 
@@ -74,19 +75,27 @@ def test_grad_accumulation_and_state_dict_filter(dev):
     assert len(lora_keys) == 2 * 4 * cfg.num_layers and all(k.startswith("base_model.model.") for k in lora_keys)
 
 
-def test_full_finetune_all_parameter_grads_match_oracle(dev):
+@pytest.mark.parametrize("variant", ["2b", "5b_rope", "5b_i2v"])
+def test_full_finetune_all_parameter_grads_match_oracle(dev, variant):
     """BASELINE config 3 (every weight trainable): loss and ALL parameter gradients of a tiny DiT against the fp64 oracle,
-    then one fused AdamW step against torch.optim.AdamW on the oracle's gradients."""
+    then one fused AdamW step against torch.optim.AdamW on the oracle's gradients.  Variants: the 2B layout (sincos
+    table), the 5B layout (rotary q/k), the 5B-I2V layout (rotary + learned table buffer + 32 input channels)."""
     import cogvideox_oracle as O
     from vt355.dit import CogVideoXTransformer3DModel
     from vt355.fullft import enable_full_finetune
     from vt355.optim import FusedAdamW
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.workflow import _LossFn
-    cfg = O.tiny_config()
-    kw = {k: getattr(cfg, k) for k in ("num_attention_heads", "attention_head_dim", "num_layers", "time_embed_dim", "text_embed_dim",
-                                       "sample_width", "sample_height", "sample_frames", "max_text_seq_length")}
-    model = CogVideoXTransformer3DModel(**kw).init_weights(11, std=0.05).to(dev)
+    from vt355.selfcheck import CFG_KEYS
+    rope, i2v = variant != "2b", variant == "5b_i2v"
+    cfg = O.tiny_config(use_rotary_positional_embeddings=rope, use_learned_positional_embeddings=i2v,
+                        in_channels=32 if i2v else 16)
+    model = CogVideoXTransformer3DModel(**{k: getattr(cfg, k) for k in CFG_KEYS}).init_weights(11, std=0.05)
+    if i2v:         # a checkpointed table differs from the sincos init, text slots included
+        gpe = torch.Generator().manual_seed(5)
+        model.patch_embed.pos_embedding.copy_((torch.randn(model.patch_embed.pos_embedding.shape, generator=gpe) * 0.1)
+                                              .to(torch.bfloat16))
+    model = model.to(dev)
     ft = enable_full_finetune(model)
     assert all(p.requires_grad for p in model.parameters())
     g = torch.Generator().manual_seed(77)
@@ -97,7 +106,18 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev):
     t = torch.tensor([150, 650])
     sched = CogVideoXDPMScheduler()
     noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
-    out = model(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    model_in = noisy
+    if i2v:
+        img = torch.zeros(x0.shape)
+        img[:, 0] = torch.randn(x0[:, 0].shape, generator=g)
+        model_in = torch.cat([noisy, img.to(dev, torch.bfloat16)], dim=2)
+    tabs = None
+    if rope:
+        grid = (cfg.sample_height // 2, cfg.sample_width // 2)
+        tabs = O.rope_3d_tables(64, O.resize_crop_region_for_grid(grid, (3, 4)), grid, Fr)
+    fwd = lambda: model(hidden_states=model_in, encoder_hidden_states=text.to(dev), timestep=t.to(dev),
+                        image_rotary_emb=None if tabs is None else (tabs[0].to(dev), tabs[1].to(dev)))[0]
+    out = fwd()
     sa, sb, w = sched.coefficients(t.to(dev))
     loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
     ft.grad.zero_()
@@ -106,7 +126,8 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev):
     Pref = {k: v.detach().float().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
     abar = O.alphas_cumprod_cogvideox()
     nref = noisy.float().cpu().double()
-    out_ref = O.dit_forward(Pref, cfg, nref, text.double(), t)
+    out_ref = O.dit_forward(Pref, cfg, model_in.float().cpu().double(), text.double(), t,
+                            image_rotary_emb=None if tabs is None else (tabs[0].double(), tabs[1].double()))
     pred = O.get_velocity(out_ref, nref, t, abar)
     wref = (1.0 / (1.0 - abar[t])).view(-1, 1, 1, 1, 1)
     loss_ref = torch.mean((wref * (pred - x0.double()) ** 2).reshape(B, -1), dim=1).mean()
@@ -116,7 +137,7 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev):
     for name in ft.names:
         gd = ft.g(name).cpu().double().reshape(-1)
         gr = Pref[name].grad.reshape(-1)
-        if name.endswith("norm_k.bias"):
+        if name.endswith("norm_k.bias") and not rope:
             # adding a constant to every key shifts all scores of a query equally: softmax is invariant and the exact
             # gradient is 0 (the oracle returns fp64 noise) -> the device value must be noise-sized, not "aligned"
             assert gr.norm() < 1e-9
@@ -144,5 +165,5 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev):
     assert (ft.flat.cpu() - pt.detach()).abs().max().item() < 1e-5
     assert (ft.flat_bf16.float().cpu() - pt.detach()).abs().max().item() < 2e-2 * pt.detach().abs().max().item()
     # the packed transposed operands follow the new weights at the next forward
-    out2 = model(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    out2 = fwd()
     assert torch.isfinite(out2.float()).all() and not torch.equal(out2, out)

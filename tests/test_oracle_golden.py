@@ -101,3 +101,46 @@ def test_oracle_train_step_runs_and_lora_zero_init_is_identity():
     for i in range(3):
         pt.grad = gr.clone(); opt.step(); O.adamw_step(p, gr, m, v, i + 1, 1e-2)
     assert torch.allclose(p, pt.detach(), atol=1e-6)
+
+
+def test_rope_tables_and_rotation_match_sat_mixin():
+    """tests/golden/rope_3d.npz: Rotary3DPositionEmbeddingMixin tables + rotary() (dit_video_concat.py:263-341)."""
+    g = np.load(os.path.join(G, "rope_3d.npz"))
+    cos, sin = O.rope_3d_tables(64, ((0, 0), (4, 5)), (4, 5), 3)
+    np.testing.assert_allclose(cos.numpy(), g["small_cos"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sin.numpy(), g["small_sin"], rtol=0, atol=1e-6)
+    rot = O.apply_rope(torch.from_numpy(g["x"]), cos, sin)
+    np.testing.assert_allclose(rot.numpy(), g["rotated"], rtol=0, atol=1e-6)
+    # full CogVideoX-5B grid 13 x 30 x 45 (49 x 480 x 720): the crop region is the whole base grid
+    crop = O.resize_crop_region_for_grid((30, 45), (30, 45))
+    assert crop == ((0, 0), (30, 45))
+    cos, sin = O.rope_3d_tables(64, crop, (30, 45), 13)
+    assert cos.shape == (17550, 64)
+    idx = g["full_rows_idx"]
+    # fp32 cos/sin of angles up to 44 rad: the two constructions may differ in the last ulp of the angle
+    np.testing.assert_allclose(cos[idx].numpy(), g["full_cos_rows"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(sin[idx].numpy(), g["full_sin_rows"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(cos.double().sum(0).numpy(), g["full_cos_colsum"], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(sin.double().sum(0).numpy(), g["full_sin_colsum"], rtol=0, atol=2e-2)
+
+
+def test_crop_region_matches_reference():
+    g = np.load(os.path.join(G, "crop_region.npz"))
+    for src, tgt, reg in zip(g["src"], g["tgt"], g["region"]):
+        got = O.resize_crop_region_for_grid(tuple(int(v) for v in src), tuple(int(v) for v in tgt))
+        assert np.array_equal(np.array(got), reg), (src, tgt, got, reg)
+
+
+def test_rope_block_is_orthogonal_and_position_relative():
+    """size-independent properties of the rotation: norm preserving; q.k depends only on the position difference
+    along an axis (here: the frame axis, spatial position fixed)."""
+    cos, sin = O.rope_3d_tables(64, ((0, 0), (2, 2)), (2, 2), 6)
+    x = torch.randn(1, 1, 24, 64, dtype=torch.float64)
+    r = O.apply_rope(x, cos.double(), sin.double())
+    np.testing.assert_allclose(r.norm(dim=-1).numpy(), x.norm(dim=-1).numpy(), rtol=1e-6)   # fp32 tables: cos^2+sin^2 = 1 +- 1e-7
+    q = torch.randn(64, dtype=torch.float64).expand(24, 64)
+    k = torch.randn(64, dtype=torch.float64).expand(24, 64)
+    rq, rk = O.apply_rope(q, cos.double(), sin.double()), O.apply_rope(k, cos.double(), sin.double())
+    # tokens (t, 0, 0) are rows 4t: <R_t q, R_{t+2} k> must not depend on t
+    dots = [float(rq[4 * t] @ rk[4 * (t + 2)]) for t in range(4)]
+    assert max(dots) - min(dots) < 1e-5

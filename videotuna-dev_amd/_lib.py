@@ -27,7 +27,7 @@ PROTOTYPES = {
                      _vp, _i, _vp, _i, _vp],
     "vt_gemm_nt_bf16": [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _f, _i, _vp],
     "vt_group_colsum": [_vp, _i, _vp, _i, _fp, _fp, _fp, _fp, _ll, _i, _i, _i, _i, _ll, _ll, _vp],
-    "vt_qk_ln_param_grads": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _fp, _ll, _i, _vp],
+    "vt_qk_ln_param_grads": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _fp, _ll, _i, _fp, _fp, _i, _i, _vp],
     "vt_ln_param_combine": [_fp, _fp, _i, _i, _vp, _vp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp],
     "vt_small_linear_bwd": [_fp, _i, _vp, _i, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "vt_silu_bwd": [_fp, _vp, _fp, _ll, _vp],
@@ -36,8 +36,8 @@ PROTOTYPES = {
                          _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
     "vt_ln_modulate_fwd": [_vp, _i, _vp, _i, _vp, _vp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "vt_ln_modulate_bwd": [_vp, _i, _vp, _i, _fp, _fp, _vp, _fp, _fp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _f, _vp],
-    "vt_qk_layernorm_bwd": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _vp, _vp, _vp, _i, _ll, _i, _vp],
+    "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _f, _fp, _fp, _i, _i, _vp],
+    "vt_qk_layernorm_bwd": [_fp, _i, _vp, _i, _vp, _i, _fp, _fp, _vp, _vp, _vp, _i, _ll, _i, _fp, _fp, _i, _i, _vp],
     "vt_gate_mul": [_vp, _i, _vp, _i, _fp, _fp, _i, _ll, _i, _i, _i, _vp],
     "vt_silu_bf16": [_vp, _vp, _ll, _vp],
     "vt_cast_f32_bf16": [_fp, _vp, _ll, _vp],

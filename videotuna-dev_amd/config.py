@@ -14,6 +14,7 @@ TARGET_REMAP = {
     "diffusers.CogVideoXDPMScheduler": "vt355.scheduler.CogVideoXDPMScheduler",
     "peft.LoraConfig": "vt355.lora.LoraConfig",
     "videotuna.models.cogvideo_hf.cogvideo_pl.CogVideoXWorkFlow": "vt355.workflow.CogVideoXWorkFlow",
+    "videotuna.models.cogvideo_hf.cogvideo_i2v.CogVideoXI2V": "vt355.workflow.CogVideoXI2V",
 }
 _NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
 

@@ -94,3 +94,22 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + orig / nx;
 }
+// rotary position embedding helpers (fp32 tables [S - St, 64]; pairs (2i, 2i+1) live in one lane's 8 elements)
+__device__ __forceinline__ void rope_load8(const float* src, float* d) {
+    f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = a[j]; d[j + 4] = b[j]; }
+}
+// transpose of the rotation: applied to an incoming gradient
+__device__ __forceinline__ void rope_bwd8(const float* rope_cos, const float* rope_sin, int spos, int sub, float* dy) {
+    float cs[8], sn[8];
+    rope_load8(rope_cos + (size_t)spos * 64 + sub * 8, cs);
+    rope_load8(rope_sin + (size_t)spos * 64 + sub * 8, sn);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float a = dy[j], b = dy[j + 1];
+        dy[j] = a * cs[j] + b * sn[j + 1];
+        dy[j + 1] = b * cs[j + 1] - a * sn[j];
+    }
+}
+

@@ -216,11 +216,14 @@ extern "C" int vt_ln_modulate_bwd(const void* dy, int lddy, const void* x, int l
 
 // ------------------------------------------------------------------------------------------------
 // per-head LayerNorm(64) of q and k.  8 lanes per (row, which, head) group of 64 elements.
+// Optional rotary position embedding (CogVideoX-5B, cogvideo_pl.py:442-473 builds the tables, diffusers'
+// CogVideoXAttnProcessor2_0 applies them to the video rows of q and k after the LayerNorm): tables are fp32 [S-St, 64].
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qk_layernorm_fwd_kernel(const bf16_t* qkv, int ld, bf16_t* out, int ldo,
                                                               const bf16_t* gq, const bf16_t* bq, const bf16_t* gk,
                                                               const bf16_t* bk, float* mean, float* rstd,
-                                                              long long M, int H, float eps, float q_scale) {
+                                                              long long M, int H, float eps, float q_scale,
+                                                              const float* rope_cos, const float* rope_sin, int S, int St) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long grp = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -252,7 +255,22 @@ __global__ __launch_bounds__(256) void qk_layernorm_fwd_kernel(const bf16_t* qkv
     const float osc = isk ? 1.0f : q_scale;     // q_hat may be pre-multiplied by softmax_scale*log2(e) for the attention kernels
     float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = ((v[j] - mu) * rs * ga[j] + be[j]) * osc;
+    for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rs * ga[j] + be[j];
+    // rotary embedding of the video rows (CogVideoX-5B): out = x*cos + rotate_pairs(x)*sin, pairs (2i, 2i+1) are lane-local
+    const int spos = rope_cos != nullptr ? (int)(m % S) - St : -1;
+    if (spos >= 0) {
+        float cs[8], sn[8];
+        rope_load8(rope_cos + (size_t)spos * 64 + sub * 8, cs);
+        rope_load8(rope_sin + (size_t)spos * 64 + sub * 8, sn);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const float a = o[j], b = o[j + 1];
+            o[j] = a * cs[j] - b * sn[j];
+            o[j + 1] = b * cs[j + 1] + a * sn[j + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= osc;
     *(u32x4*)(out + (size_t)m * ldo + wh * 64 + sub * 8) = pack8(o);
     if (sub == 0) { mean[m * 2 * H + wh] = mu; rstd[m * 2 * H + wh] = rs; }
 }
@@ -261,7 +279,8 @@ __global__ __launch_bounds__(256) void qk_layernorm_fwd_kernel(const bf16_t* qkv
 __global__ __launch_bounds__(256) void qk_layernorm_bwd_kernel(const float* dqh, int lddq, const bf16_t* dkh, int lddk,
                                                               const bf16_t* qkv, int ld, const float* mean,
                                                               const float* rstd, const bf16_t* gq, const bf16_t* gk,
-                                                              bf16_t* dqkv, int ldd, long long M, int H) {
+                                                              bf16_t* dqkv, int ldd, long long M, int H,
+                                                              const float* rope_cos, const float* rope_sin, int S, int St) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long grp = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -284,6 +303,8 @@ __global__ __launch_bounds__(256) void qk_layernorm_bwd_kernel(const float* dqh,
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dy[j] = a[j]; dy[j + 4] = b[j]; }
         }
+        const int spos = rope_cos != nullptr ? (int)(m % S) - St : -1;
+        if (spos >= 0) rope_bwd8(rope_cos, rope_sin, spos, sub, dy);
         unpack8(*(const u32x4*)(qkv + (size_t)m * ld + wh * 64 + sub * 8), xv);
         unpack8(*(const u32x4*)((isk ? gk : gq) + sub * 8), ga);
 #pragma unroll
@@ -307,8 +328,12 @@ __global__ __launch_bounds__(256) void qk_layernorm_bwd_kernel(const float* dqh,
 
 extern "C" int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, const void* gq, const void* bq,
                                    const void* gk, const void* bk, float* mean, float* rstd,
-                                   long long M, int H, float eps, float q_scale, void* stream) {
+                                   long long M, int H, float eps, float q_scale,
+                                   const float* rope_cos, const float* rope_sin, int S, int St, void* stream) {
     if (M <= 0 || H <= 0 || (ld % 8) || (ldo % 8) || ld < 2 * H * 64 || ldo < 2 * H * 64) return VT_ERR_BAD_SHAPE;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return VT_ERR_BAD_SHAPE;
+    if (rope_cos != nullptr && (S <= 0 || St < 0 || St > S || (M % S))) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) return VT_ERR_BAD_ALIGN;
     if ((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)gq) | ((uintptr_t)bq) | ((uintptr_t)gk) | ((uintptr_t)bk)) & 15)
         return VT_ERR_BAD_ALIGN;
     const long long threads = M * 2 * H * 8;
@@ -316,14 +341,19 @@ extern "C" int vt_qk_layernorm_fwd(const void* qkv, int ld, void* out, int ldo, 
     if (blocks > 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(qk_layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)qkv, ld, (bf16_t*)out, ldo, (const bf16_t*)gq, (const bf16_t*)bq,
-                       (const bf16_t*)gk, (const bf16_t*)bk, mean, rstd, M, H, eps, q_scale);
+                       (const bf16_t*)gk, (const bf16_t*)bk, mean, rstd, M, H, eps, q_scale, rope_cos, rope_sin,
+                       S > 0 ? S : 1, St);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 
 extern "C" int vt_qk_layernorm_bwd(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
                                    const float* mean, const float* rstd, const void* gq, const void* gk,
-                                   void* dqkv, int ldd, long long M, int H, void* stream) {
+                                   void* dqkv, int ldd, long long M, int H,
+                                   const float* rope_cos, const float* rope_sin, int S, int St, void* stream) {
     if (M <= 0 || H <= 0 || (ld % 8) || (ldd % 8) || (lddq % 4) || (lddk % 8)) return VT_ERR_BAD_SHAPE;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return VT_ERR_BAD_SHAPE;
+    if (rope_cos != nullptr && (S <= 0 || St < 0 || St > S || (M % S))) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) return VT_ERR_BAD_ALIGN;
     if ((((uintptr_t)qkv) | ((uintptr_t)dqkv) | ((uintptr_t)dq_hat) | ((uintptr_t)dk_hat) | ((uintptr_t)gq) | ((uintptr_t)gk)) & 15)
         return VT_ERR_BAD_ALIGN;
     const long long threads = M * 2 * H * 8;
@@ -331,6 +361,6 @@ extern "C" int vt_qk_layernorm_bwd(const float* dq_hat, int lddq, const void* dk
     if (blocks > 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(qk_layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        dq_hat, lddq, (const bf16_t*)dk_hat, lddk, (const bf16_t*)qkv, ld, mean, rstd,
-                       (const bf16_t*)gq, (const bf16_t*)gk, (bf16_t*)dqkv, ldd, M, H);
+                       (const bf16_t*)gq, (const bf16_t*)gk, (bf16_t*)dqkv, ldd, M, H, rope_cos, rope_sin, S > 0 ? S : 1, St);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

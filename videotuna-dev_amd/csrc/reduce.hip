@@ -102,7 +102,8 @@ extern "C" int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, c
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qk_ln_param_grads_kernel(const float* dqh, int lddq, const bf16_t* dkh, int lddk,
                                                                const bf16_t* qkv, int ld, const float* mean, const float* rstd,
-                                                               float* out, long long M, int H) {
+                                                               float* out, long long M, int H,
+                                                               const float* rope_cos, const float* rope_sin, int S, int St) {
     __shared__ float red[4][2][2][64];       // [wave][which][gamma/beta][e]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 7;                // 8 lanes per 64-element group
@@ -127,6 +128,8 @@ __global__ __launch_bounds__(256) void qk_ln_param_grads_kernel(const float* dqh
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dy[j] = a[j]; dy[j + 4] = b[j]; }
         }
+        const int spos = rope_cos != nullptr ? (int)(m % S) - St : -1;
+        if (spos >= 0) rope_bwd8(rope_cos, rope_sin, spos, sub, dy);
         unpack8(*(const u32x4*)(qkv + (size_t)m * ld + wh * 64 + sub * 8), xv);
         const int w = isk ? 1 : 0;
 #pragma unroll
@@ -148,12 +151,15 @@ __global__ __launch_bounds__(256) void qk_ln_param_grads_kernel(const float* dqh
     atomicAdd(out + (w * 2 + gb) * 64 + e, red[0][w][gb][e] + red[1][w][gb][e] + red[2][w][gb][e] + red[3][w][gb][e]);
 }
 extern "C" int vt_qk_ln_param_grads(const float* dq_hat, int lddq, const void* dk_hat, int lddk, const void* qkv, int ld,
-                                    const float* mean, const float* rstd, float* out_2x2x64, long long M, int H, void* stream) {
+                                    const float* mean, const float* rstd, float* out_2x2x64, long long M, int H,
+                                    const float* rope_cos, const float* rope_sin, int S, int St, void* stream) {
     if (M <= 0 || H <= 0 || (ld % 8) || (lddq % 4) || (lddk % 8)) return VT_ERR_BAD_SHAPE;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return VT_ERR_BAD_SHAPE;
+    if (rope_cos != nullptr && (S <= 0 || St < 0 || St > S || (M % S))) return VT_ERR_BAD_SHAPE;
     long long groups = M * 2 * H;
     int blocks = (int)((groups + 31) / 32 > 1024 ? 1024 : (groups + 31) / 32);
     hipLaunchKernelGGL(qk_ln_param_grads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dq_hat, lddq, (const bf16_t*)dk_hat,
-                       lddk, (const bf16_t*)qkv, ld, mean, rstd, out_2x2x64, M, H);
+                       lddk, (const bf16_t*)qkv, ld, mean, rstd, out_2x2x64, M, H, rope_cos, rope_sin, S > 0 ? S : 1, St);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -136,8 +136,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         c = self.config
         if c.attention_head_dim != 64:
             raise NotImplementedError("the HIP attention kernels are specialised for head_dim 64")
-        if c.use_rotary_positional_embeddings:
-            raise NotImplementedError("RoPE (CogVideoX-5B) is not built yet; 2B uses the sincos table")
+        if c.use_learned_positional_embeddings and not c.use_rotary_positional_embeddings:
+            raise ValueError("learned positional embeddings come with RoPE (CogVideoX-5B-I2V); 2B uses the fixed sincos table")
         d = c.num_attention_heads * c.attention_head_dim
         if d % 64 or c.time_embed_dim % 64 or c.text_embed_dim % 64 or (c.in_channels * c.patch_size ** 2) % 64:
             raise NotImplementedError("inner dims must be multiples of 64 (GEMM K-tile)")
@@ -145,6 +145,15 @@ class CogVideoXTransformer3DModel(nn.Module):
         pe = _Container()
         pe.proj = PatchProj(c.in_channels, d, c.patch_size)
         pe.text_proj = Linear(c.text_embed_dim, d)
+        if c.use_learned_positional_embeddings:
+            # CogVideoX-5B-I2V: a persistent (checkpointed, never trained) [1, max_text + patches, d] buffer, initialised
+            # with the sincos table, added to the joint sequence; fixed to the configured sample size
+            frames = (c.sample_frames - 1) // c.temporal_compression_ratio + 1
+            tab = sincos_pos_embed_3d(d, c.sample_height // c.patch_size, c.sample_width // c.patch_size, frames,
+                                      c.spatial_interpolation_scale, c.temporal_interpolation_scale)
+            full = torch.zeros(1, c.max_text_seq_length + tab.shape[0], d, dtype=BF16)
+            full[0, c.max_text_seq_length:] = torch.from_numpy(tab).to(torch.float32).to(BF16)
+            pe.register_buffer("pos_embedding", full, persistent=True)
         self.patch_embed = pe
         te = _Container()
         te.linear_1, te.linear_2 = Linear(d, c.time_embed_dim), Linear(c.time_embed_dim, c.time_embed_dim)
@@ -210,7 +219,8 @@ class CogVideoXTransformer3DModel(nn.Module):
         sd = {}
         for f in files:
             sd.update(load_file(os.path.join(root, f)))
-        sd.pop("patch_embed.pos_embedding", None)       # fixed buffer, regenerated
+        if not model.config.use_learned_positional_embeddings:
+            sd.pop("patch_embed.pos_embedding", None)   # fixed buffer, regenerated
         model.load_state_dict({k: v.to(BF16) for k, v in sd.items()}, strict=True)
         return model
 
@@ -232,18 +242,30 @@ class CogVideoXTransformer3DModel(nn.Module):
     # ----- forward -----
     def forward(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, image_rotary_emb=None,
                 return_dict: bool = False, **unused):
-        if image_rotary_emb is not None:
-            raise NotImplementedError("image_rotary_emb (CogVideoX-5B RoPE) is not supported by this engine yet")
+        if (image_rotary_emb is not None) != bool(self.config.use_rotary_positional_embeddings):
+            raise ValueError("image_rotary_emb=(cos, sin) must be given exactly when config.use_rotary_positional_embeddings "
+                             "is set (CogVideoX-5B recipes; cogvideo_pl.py:846-859)")
         if not hidden_states.is_cuda:
             raise RuntimeError("vt355 CogVideoXTransformer3DModel runs only on an MI355X device (no CPU fallback)")
         from .engine import dit_apply
-        out = dit_apply(self, hidden_states, encoder_hidden_states, timestep)
+        out = dit_apply(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb)
         if return_dict:
             return SimpleNamespace(sample=out)
         return (out,)
 
     # ----- positional table -----
-    def pos_table(self, frames: int, height: int, width: int, device) -> torch.Tensor:
+    def pos_table(self, frames: int, height: int, width: int, device):
+        """bf16 [Sv, d] table added to the video tokens (None for the RoPE models without a learned table)"""
+        c = self.config
+        if c.use_learned_positional_embeddings:
+            tab = self.patch_embed.pos_embedding
+            Sv = frames * (height // c.patch_size) * (width // c.patch_size)
+            if tab.shape[1] != c.max_text_seq_length + Sv:
+                raise ValueError(f"learned positional embeddings are fixed to the configured sample size "
+                                 f"({tab.shape[1] - c.max_text_seq_length} patches), got {Sv}")
+            return tab[0, c.max_text_seq_length:]
+        if c.use_rotary_positional_embeddings:
+            return None
         key = (frames, height, width, str(device))
         if key not in self._pos_cache:
             c = self.config

@@ -126,7 +126,7 @@ def _mod(mod: torch.Tensor, idx: int, d: int):
 
 
 # ---------------------------------------------------------------------------------------------------
-def run_forward(model, x, text, t, save: bool):
+def run_forward(model, x, text, t, save: bool, rope=None):
     c = model.config
     P = packed(model)
     st = model.lora
@@ -154,11 +154,20 @@ def run_forward(model, x, text, t, save: bool):
     # ---- patch / text embedding into the joint [text, video] sequence ----
     h = E(M, d)
     patches = E(B * Sv, C * p * p); ops.patchify(x, patches, p)
-    pos = model.pos_table(Fr, Hh, Ww, dev)
+    pos = model.pos_table(Fr, Hh, Ww, dev)          # None: RoPE model without a learned table
+    pos_txt = model.patch_embed.pos_embedding[0, :St] if c.use_learned_positional_embeddings else None
     for b in range(B):
-        ops.gemm(patches[b * Sv:(b + 1) * Sv], P.patch_w, h[b * S + St:(b + 1) * S], P.patch_b,
-                 epilogue=EPI_GATED_RES, residual=pos)
-        ops.gemm(text[b], P.text_w, h[b * S:b * S + St], P.text_b)
+        if pos is not None:
+            ops.gemm(patches[b * Sv:(b + 1) * Sv], P.patch_w, h[b * S + St:(b + 1) * S], P.patch_b,
+                     epilogue=EPI_GATED_RES, residual=pos)
+        else:
+            ops.gemm(patches[b * Sv:(b + 1) * Sv], P.patch_w, h[b * S + St:(b + 1) * S], P.patch_b)
+        if pos_txt is not None:
+            ops.gemm(text[b], P.text_w, h[b * S:b * S + St], P.text_b, epilogue=EPI_GATED_RES, residual=pos_txt)
+        else:
+            ops.gemm(text[b], P.text_w, h[b * S:b * S + St], P.text_b)
+    if rope is not None:
+        rope = (rope[0], rope[1], S, St)
 
     saved: List[SimpleNamespace] = []
     xg = E(M, d)                    # transient: norm2 output
@@ -178,7 +187,7 @@ def run_forward(model, x, text, t, save: bool):
         ops.gemm(x1, Lw.w_qkv, qkv, Lw.b_qkv, K=KE)
         qkh = E(M, 2 * d)
         a.qmean, a.qrstd = E(M, 2 * H, dt=torch.float32), E(M, 2 * H, dt=torch.float32)
-        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6, q_scale=Q_PRESCALE)
+        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6, q_scale=Q_PRESCALE, rope=rope)
         o = E(M, d + EXT)
         lse = E(B, H, S, dt=torch.float32)
         qk3, qkv3, o3 = qkh.view(B, S, 2 * d), qkv.view(B, S, 3 * d), o.view(B, S, d + EXT)
@@ -227,7 +236,7 @@ def run_forward(model, x, text, t, save: bool):
     ctx = None
     if save:
         ctx = SimpleNamespace(blocks=saved, mod=mod, h_last=h, y1=y1, fm1=fm1, fr1=fr1, fm2=fm2, fr2=fr2,
-                              dims=(B, Fr, C, Hh, Ww, S, St, Sv, M), f_scale=f_scale)
+                              dims=(B, Fr, C, Hh, Ww, S, St, Sv, M), f_scale=f_scale, rope=rope)
         if ft is not None:
             ctx.y2, ctx.tsin, ctx.e1_pre, ctx.e1, ctx.emb_pre, ctx.se, ctx.patches, ctx.text = y2, tsin, e1_pre, e1, emb_pre, emb, patches, text
     return out, ctx
@@ -246,7 +255,7 @@ def run_backward(model, ctx, dout: torch.Tensor):
     mod = ctx.mod
 
     # ---- final layers ----
-    dtok = E(B * Sv, C * p * p); ops.patchify(dout, dtok, p)
+    dtok = E(B * Sv, c.out_channels * p * p); ops.patchify(dout, dtok, p)
     dy2 = E(B * Sv, d); ops.gemm(dtok, P.proj_w_t, dy2, None)
     dy1 = E(B * Sv, d)
     ops.ln_modulate_bwd(dy2, ctx.y1, ctx.fm2, ctx.fr2, model.norm_out.norm.weight, (ctx.f_scale, ctx.f_scale, mod.stride(0)),
@@ -288,7 +297,7 @@ def run_backward(model, ctx, dout: torch.Tensor):
         ops.attn_bwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], a.o.view(B, S, d + EXT)[:, :, :d],
                      dO.view(B, S, d + EXT)[:, :, :d], a.lse, delta, dq, dkh.view(B, S, d),
                      dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S, q_prescaled=True)
-        ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H)
+        ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H, rope=ctx.rope)
         ops.gemm(dqkv, Lw.w_qkv_t, dx1, None)                             # [M, d+EXT]: dx1 | dT1
         for j in range(3):
             ops.skinny_tn(dqkv[:, j * d:], a.x1[:, d + j * r:], r, st.b_qkv(st.grad, i)[j * d:], r, 1, st.scaling, d)
@@ -304,8 +313,8 @@ def run_backward(model, ctx, dout: torch.Tensor):
 
 class _DiTFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, x, text, t):
-        out, saved = run_forward(model, x, text, t, save=True)
+    def forward(ctx, anchor, model, x, text, t, rope):
+        out, saved = run_forward(model, x, text, t, save=True, rope=rope)
         ctx.model, ctx.saved = model, saved
         return out
 
@@ -317,10 +326,23 @@ class _DiTFn(torch.autograd.Function):
         else:
             run_backward(ctx.model, ctx.saved, dout.contiguous())
         ctx.saved = None
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
-def dit_apply(model, hidden_states, encoder_hidden_states, timestep):
+def _rope_tables(model, image_rotary_emb, Sv: int, dev):
+    """(cos, sin) as handed over by the workflow (cogvideo_pl.py:846-859) -> contiguous fp32 [Sv, 64] on the device"""
+    if image_rotary_emb is None:
+        return None
+    cos, sin = image_rotary_emb
+    out = []
+    for tb in (cos, sin):
+        if tuple(tb.shape) != (Sv, model.config.attention_head_dim):
+            raise ValueError(f"image_rotary_emb tables must be [{Sv}, {model.config.attention_head_dim}], got {tuple(tb.shape)}")
+        out.append(tb.detach().to(device=dev, dtype=torch.float32).contiguous())
+    return out[0], out[1]
+
+
+def dit_apply(model, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None):
     x = hidden_states
     if x.dtype != BF16:
         raise TypeError(f"hidden_states must be bf16 (model dtype), got {x.dtype}")
@@ -337,8 +359,10 @@ def dit_apply(model, hidden_states, encoder_hidden_states, timestep):
     st = model.lora
     need_grad = torch.is_grad_enabled() and ((st is not None and any(p.requires_grad for p in st.params))
                                              or getattr(model, "fullft", None) is not None)
+    p = model.config.patch_size
+    rope = _rope_tables(model, image_rotary_emb, x.shape[1] * (x.shape[3] // p) * (x.shape[4] // p), x.device)
     if not need_grad:
-        out, _ = run_forward(model, x, text, t, save=False)
+        out, _ = run_forward(model, x, text, t, save=False, rope=rope)
         return out
     anchor = torch.zeros(1, device=x.device, requires_grad=True)
-    return _DiTFn.apply(anchor, model, x, text, t)
+    return _DiTFn.apply(anchor, model, x, text, t, rope)

@@ -73,9 +73,10 @@ def run_backward_fullft(model, ctx, dout: torch.Tensor, on_grads_ready: Optional
         ops.ln_param_combine(G1, G2, d, gam, bet, m_scales, g(gamma_name), g(beta_name), dm_slots, True)
 
     # ---------------- final layers ----------------
-    dtok = E(B * Sv, C * p * p); ops.patchify(dout, dtok, p)
-    _dw(dtok, ctx.y2, g("proj_out.weight"), C * p * p, d)
-    ops.group_colsum(dtok, g("proj_out.bias"), D=C * p * p)
+    Co = c.out_channels                 # I2V: in_channels (video | image latents) = 2 * out_channels
+    dtok = E(B * Sv, Co * p * p); ops.patchify(dout, dtok, p)
+    _dw(dtok, ctx.y2, g("proj_out.weight"), Co * p * p, d)
+    ops.group_colsum(dtok, g("proj_out.bias"), D=Co * p * p)
     dy2 = E(B * Sv, d); ops.gemm(dtok, P.proj_w_t, dy2, None)
     mo = 2 * L * 6 * d
     f_dshift, f_dscale = dmod[:, mo:], dmod[:, mo + d:]
@@ -130,8 +131,8 @@ def run_backward_fullft(model, ctx, dout: torch.Tensor, on_grads_ready: Optional
                      dO.view(B, S, d), a.lse, delta, dq, dkh.view(B, S, d), dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S,
                      q_prescaled=True)
         # q/k LayerNorm parameters: the four 64-vectors are adjacent in the flat layout -> written in place
-        ops.qk_ln_param_grads(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, g(pre + "attn1.norm_q.weight"), H)
-        ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H)
+        ops.qk_ln_param_grads(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, g(pre + "attn1.norm_q.weight"), H, rope=ctx.rope)
+        ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H, rope=ctx.rope)
         gw_qkv = ft.span(ft.grad, pre + "attn1.to_q.weight", pre + "attn1.to_v.weight", (3 * d, d))
         gb_qkv = ft.span(ft.grad, pre + "attn1.to_q.bias", pre + "attn1.to_v.bias", (3 * d,))
         _dw(dqkv, a.x1, gw_qkv, 3 * d, d)

@@ -121,10 +121,25 @@ def group_colsum(x, out1, y=None, out2=None, mean=None, rstd=None, D: Optional[i
           "vt_group_colsum")
 
 
-def qk_ln_param_grads(dq_hat_f32, dk_hat, qkv, mean, rstd, out, H: int):
+def _rope_args(rope, M: int):
+    """rope = None or (cos, sin, S, St): fp32 [S-St, 64] tables for the video rows of every sample"""
+    if rope is None:
+        return None, None, 0, 0
+    cos, sin, S, St = rope
+    for t in (cos, sin):
+        _req(t, torch.float32, "rope table", 2)
+        if tuple(t.shape) != (S - St, 64) or not t.is_contiguous():
+            raise ValueError(f"rope table must be contiguous [{S - St}, 64], got {tuple(t.shape)}")
+    if M % S:
+        raise ValueError(f"rows {M} not a multiple of the sequence length {S}")
+    return cos.data_ptr(), sin.data_ptr(), S, St
+
+
+def qk_ln_param_grads(dq_hat_f32, dk_hat, qkv, mean, rstd, out, H: int, rope=None):
+    rc, rsn, S, St = _rope_args(rope, qkv.shape[0])
     check(load_library().vt_qk_ln_param_grads(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
                                               qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), out.data_ptr(),
-                                              qkv.shape[0], H, _stream()), "vt_qk_ln_param_grads")
+                                              qkv.shape[0], H, rc, rsn, S, St, _stream()), "vt_qk_ln_param_grads")
 
 
 def ln_param_combine(G1, G2, D: int, gamma, beta, scales, dgamma, dbeta, dmods, grouped: bool):
@@ -200,20 +215,23 @@ def ln_modulate_bwd(dy, x, mean, rstd, gamma, scales, dres, dx, D: int, S: int, 
                                  dx.data_ptr(), dx.stride(0), x.shape[0], D, S, St, _stream()), "vt_ln_modulate_bwd")
 
 
-def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float, q_scale: float = 1.0):
+def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float, q_scale: float = 1.0, rope=None):
     _req(qkv, BF16, "qkv", 2); _req(out, BF16, "out", 2)
     lib = load_library()
+    rc, rsn, S, St = _rope_args(rope, qkv.shape[0])
     check(lib.vt_qk_layernorm_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), bq.data_ptr(),
                                   gk.data_ptr(), bk.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.shape[0], H, eps,
-                                  q_scale, _stream()), "vt_qk_layernorm_fwd")
+                                  q_scale, rc, rsn, S, St, _stream()), "vt_qk_layernorm_fwd")
 
 
-def qk_layernorm_bwd(dq_hat_f32, dk_hat, qkv, mean, rstd, gq, gk, dqkv, H: int):
+def qk_layernorm_bwd(dq_hat_f32, dk_hat, qkv, mean, rstd, gq, gk, dqkv, H: int, rope=None):
     _req(dq_hat_f32, torch.float32, "dq_hat", 2); _req(dk_hat, BF16, "dk_hat", 2)
     lib = load_library()
+    rc, rsn, S, St = _rope_args(rope, qkv.shape[0])
     check(lib.vt_qk_layernorm_bwd(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
                                   qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), gq.data_ptr(), gk.data_ptr(),
-                                  dqkv.data_ptr(), dqkv.stride(0), qkv.shape[0], H, _stream()), "vt_qk_layernorm_bwd")
+                                  dqkv.data_ptr(), dqkv.stride(0), qkv.shape[0], H, rc, rsn, S, St, _stream()),
+          "vt_qk_layernorm_bwd")
 
 
 def gate_mul(x, y, g_txt, g_vid, bstride: int, D: int, S: int, St: int):

@@ -1,0 +1,68 @@
+"""3D rotary position tables of the CogVideoX-5B recipes (configs/004_cogvideox/cogvideo5b*.yaml).
+
+Host-side table construction only (a few hundred KB, built once per latent shape and cached on the device); the
+rotation itself is fused into the per-head q/k LayerNorm kernels (csrc/norm.hip, csrc/reduce.hip).
+
+Reference: CogVideoXWorkFlow._prepare_rotary_positional_embeddings (videotuna/models/cogvideo_hf/cogvideo_pl.py:442-473)
+           -> get_resize_crop_region_for_grid (videotuna/utils/common_utils.py:28-49)
+           -> diffusers.models.embeddings.get_3d_rotary_pos_embed (third party; same construction as the in-tree
+              SAT Rotary3DPositionEmbeddingMixin, videotuna/models/cogvideo_sat/dit_video_concat.py:263-320).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+
+def get_resize_crop_region_for_grid(src: Tuple[int, int], target: Tuple[int, int]):
+    """src (h, w) fitted into target (h, w) with its aspect ratio kept -> ((top, left), (bottom, right))"""
+    h, w = src
+    th, tw = target
+    if h / w > th / tw:
+        new_h, new_w = th, int(round(th / h * w))
+    else:
+        new_h, new_w = int(round(tw / w * h)), tw
+    top = int(round((th - new_h) / 2.0))
+    left = int(round((tw - new_w) / 2.0))
+    return (top, left), (top + new_h, left + new_w)
+
+
+def _axis_table(dim: int, positions: np.ndarray, theta: float):
+    inv = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    ang = torch.outer(torch.from_numpy(np.ascontiguousarray(positions, dtype=np.float32)), inv)
+    return torch.repeat_interleave(ang.cos(), 2, dim=1), torch.repeat_interleave(ang.sin(), 2, dim=1)
+
+
+def get_3d_rotary_pos_embed(embed_dim: int, crops_coords, grid_size: Tuple[int, int], temporal_size: int,
+                            theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(cos, sin), each fp32 [temporal_size * grid_h * grid_w, embed_dim], token order (t h w).
+    embed_dim is the attention head width; it is split 1/4 : 3/8 : 3/8 over (t, h, w)."""
+    (top, left), (bottom, right) = crops_coords
+    gh, gw = grid_size
+    T = temporal_size
+    tabs = [_axis_table(embed_dim // 4, np.arange(T), theta),
+            _axis_table(embed_dim // 8 * 3, np.linspace(top, bottom, gh, endpoint=False), theta),
+            _axis_table(embed_dim // 8 * 3, np.linspace(left, right, gw, endpoint=False), theta)]
+    out = []
+    for k in (0, 1):
+        t, h, w = tabs[0][k], tabs[1][k], tabs[2][k]
+        full = torch.empty(T, gh, gw, embed_dim, dtype=torch.float32)
+        dt, dh = t.shape[1], h.shape[1]
+        full[..., :dt] = t[:, None, None, :]
+        full[..., dt:dt + dh] = h[None, :, None, :]
+        full[..., dt + dh:] = w[None, None, :, :]
+        out.append(full.reshape(T * gh * gw, embed_dim))
+    return out[0], out[1]
+
+
+def prepare_rotary_positional_embeddings(height: int, width: int, num_frames: int, vae_scale_factor_spatial: int = 8,
+                                         patch_size: int = 2, attention_head_dim: int = 64, device=None,
+                                         base_height: int = 480, base_width: int = 720):
+    """pixel height/width + latent frame count -> (freqs_cos, freqs_sin) on `device` (cogvideo_pl.py:442-473)"""
+    cell = vae_scale_factor_spatial * patch_size
+    grid = (height // cell, width // cell)
+    base = (base_height // cell, base_width // cell)
+    cos, sin = get_3d_rotary_pos_embed(attention_head_dim, get_resize_crop_region_for_grid(grid, base), grid, num_frames)
+    return cos.to(device=device), sin.to(device=device)

@@ -5,14 +5,17 @@ from __future__ import annotations
 import torch
 
 
-def build_tiny(device, layers=2, heads=2, seed=0, lora_b_random=True):
+CFG_KEYS = ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers", "time_embed_dim",
+            "text_embed_dim", "patch_size", "sample_width", "sample_height", "sample_frames", "max_text_seq_length",
+            "use_rotary_positional_embeddings", "use_learned_positional_embeddings")
+
+
+def build_tiny(device, layers=2, heads=2, seed=0, lora_b_random=True, **cfg_kw):
     import cogvideox_oracle as O
     from .dit import CogVideoXTransformer3DModel
     from .lora import LoraConfig, get_peft_model
-    cfg = O.tiny_config(num_layers=layers, num_attention_heads=heads)
-    kw = {k: getattr(cfg, k) for k in ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers",
-                                       "time_embed_dim", "text_embed_dim", "patch_size", "sample_width", "sample_height",
-                                       "sample_frames", "max_text_seq_length")}
+    cfg = O.tiny_config(num_layers=layers, num_attention_heads=heads, **cfg_kw)
+    kw = {k: getattr(cfg, k) for k in CFG_KEYS}
     model = CogVideoXTransformer3DModel(**kw).init_weights(seed).to(device)
     model.requires_grad_(False)
     peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
@@ -42,13 +45,13 @@ def oracle_params(model, st, dtype=torch.float32):
     return P, Lo
 
 
-def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2):
+def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2, rope=False):
     import cogvideox_oracle as O
     from .scheduler import CogVideoXDPMScheduler
     from .workflow import _LossFn
     from .optim import FusedAdamW
     dev = torch.device("cuda:0")
-    cfg, model, peft, st = build_tiny(dev)
+    cfg, model, peft, st = build_tiny(dev, use_rotary_positional_embeddings=rope)
     g = torch.Generator().manual_seed(123)
     Fr = (cfg.sample_frames - 1) // 4 + 1
     x0 = torch.randn(B, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g)
@@ -58,7 +61,12 @@ def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2):
     sched = CogVideoXDPMScheduler()
     # ---- device path ----
     noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
-    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev), return_dict=False)[0]
+    rope_tabs = None
+    if rope:        # tiny 6x8 latent grid against a 3x4 patch base grid: the 5B table construction, small
+        rope_tabs = O.rope_3d_tables(64, O.resize_crop_region_for_grid((cfg.sample_height // 2, cfg.sample_width // 2), (3, 4)),
+                                     (cfg.sample_height // 2, cfg.sample_width // 2), Fr)
+    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev), return_dict=False,
+               image_rotary_emb=None if rope_tabs is None else (rope_tabs[0].to(dev), rope_tabs[1].to(dev)))[0]
     sa, sb, w = sched.coefficients(t.to(dev))
     loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
     st.grad.zero_()
@@ -69,7 +77,8 @@ def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2):
         v.requires_grad_(True)
     abar = O.alphas_cumprod_cogvideox()
     noisy_ref = noisy.float().cpu().double()
-    out_ref = O.dit_forward(P, cfg, noisy_ref, text.double(), t, Lo, st.scaling)
+    out_ref = O.dit_forward(P, cfg, noisy_ref, text.double(), t, Lo, st.scaling,
+                            image_rotary_emb=None if rope_tabs is None else (rope_tabs[0].double(), rope_tabs[1].double()))
     pred = O.get_velocity(out_ref, noisy_ref, t, abar)
     wref = (1.0 / (1.0 - abar[t])).view(-1, 1, 1, 1, 1)
     loss_ref = torch.mean((wref * (pred - x0.double()) ** 2).reshape(B, -1), dim=1).mean()

@@ -18,6 +18,7 @@ from . import ops
 from .config import instantiate_from_config
 from .lora import LoraConfig, get_peft_model
 from .optim import FusedAdamW
+from .rope import prepare_rotary_positional_embeddings
 
 
 class _LossFn(torch.autograd.Function):
@@ -58,6 +59,7 @@ class CogVideoXWorkFlow(nn.Module):
             self.inject_adapter(adapter_config)
         self.model.enable_gradient_checkpointing()
         self.global_step = 0
+        self._rope_cache: Dict[tuple, Any] = {}
 
     @property
     def dtype(self):
@@ -115,10 +117,78 @@ class CogVideoXWorkFlow(nn.Module):
         timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=x0.device).long()
         return self.loss_from(x0, prompt_embeds, noise, timesteps)
 
-    def loss_from(self, x0, prompt_embeds, noise, timesteps):
-        """Deterministic core of training_step (fixed noise / t) -- what the parity tests call."""
+    def _prepare_rotary_positional_embeddings(self, height: int, width: int, num_frames: int,
+                                              vae_scale_factor_spatial: int = 8, patch_size: int = 2,
+                                              attention_head_dim: int = 64, device=None, base_height: int = 480,
+                                              base_width: int = 720):
+        """(freqs_cos, freqs_sin) for pixel height/width and latent frame count (cogvideo_pl.py:442-473); cached."""
+        key = (height, width, num_frames, vae_scale_factor_spatial, patch_size, attention_head_dim, str(device),
+               base_height, base_width)
+        if key not in self._rope_cache:
+            self._rope_cache[key] = prepare_rotary_positional_embeddings(
+                height, width, num_frames, vae_scale_factor_spatial, patch_size, attention_head_dim, device,
+                base_height, base_width)
+        return self._rope_cache[key]
+
+    def loss_from(self, x0, prompt_embeds, noise, timesteps, image_latents=None):
+        """Deterministic core of training_step (fixed noise / t) -- what the parity tests call.
+        image_latents [B,F,C,H,W] (I2V): concatenated to the noisy latents along the channel axis (cogvideo_i2v.py:158)."""
         noisy = self.scheduler.add_noise(x0, noise, timesteps)
-        out = self.model(hidden_states=noisy, encoder_hidden_states=prompt_embeds, timestep=timesteps,
-                         image_rotary_emb=None, return_dict=False)[0]
+        cfg = getattr(self.model, "config", None) or self.model.base_model.config
+        image_rotary_emb = None
+        if cfg.use_rotary_positional_embeddings:        # cogvideo_pl.py:846-859
+            _, num_frames, _, height, width = x0.shape
+            image_rotary_emb = self._prepare_rotary_positional_embeddings(
+                height=height * self.vae_scale_factor_spatial, width=width * self.vae_scale_factor_spatial,
+                num_frames=num_frames, vae_scale_factor_spatial=self.vae_scale_factor_spatial,
+                patch_size=cfg.patch_size, attention_head_dim=cfg.attention_head_dim, device=x0.device)
+        model_in = noisy if image_latents is None else torch.cat([noisy, image_latents.to(noisy.dtype)], dim=2)
+        out = self.model(hidden_states=model_in, encoder_hidden_states=prompt_embeds, timestep=timesteps,
+                         image_rotary_emb=image_rotary_emb, return_dict=False)[0]
         sa, sb, w = self.scheduler.coefficients(timesteps)
         return _LossFn.apply(out, noisy, x0, sa, sb, w)
+
+
+class CogVideoXI2V(CogVideoXWorkFlow):
+    """Image-to-video finetune workflow (videotuna/models/cogvideo_hf/cogvideo_i2v.py:39-181): the first-frame image
+    latent, zero-padded over the remaining latent frames, rides along as 16 extra input channels; the loss is taken
+    on the 16 video channels only.  Pre-encoded batch: {"latents" [B,C,F,H,W], "image_latents" [B,C,1,H,W],
+    "prompt_embeds"}; the reference schema {"video","image","caption"} needs the user-supplied frozen encoders."""
+
+    def __init__(self, first_stage_config=None, cond_stage_config=None, denoiser_config=None, scheduler_config=None,
+                 learning_rate: float = 6e-6, adapter_config=None, noised_image_input: bool = False,
+                 noised_image_dropout: float = 0.05, logdir=None, first_stage=None, cond_stage=None):
+        super().__init__(first_stage_config, cond_stage_config, denoiser_config, scheduler_config, learning_rate,
+                         adapter_config, logdir, first_stage=first_stage, cond_stage=cond_stage)
+        self.noised_image_input = noised_image_input
+        self.noised_image_dropout = noised_image_dropout
+
+    def get_batch_input(self, batch):
+        if "latents" in batch:
+            vids, imgs = batch["latents"], batch["image_latents"]
+            emb = batch["prompt_embeds"]
+        else:
+            if self.first_stage is None or self.cond_stage is None:
+                raise RuntimeError("batch has the reference schema {'video','image','caption'} but no frozen VAE / T5 encoder "
+                                   "was given (outside this engine's hot path, SURVEY 8(f)); pass pre-encoded "
+                                   "{'latents','image_latents','prompt_embeds'}")
+            with torch.no_grad():
+                vids = torch.cat([self.first_stage(v) for v in batch["video"]], dim=0)
+                imgs = torch.cat([self.first_stage(im.unsqueeze(1)) for im in batch["image"]], dim=0)
+                emb = self.cond_stage([c for c in batch["caption"]])
+        vids = vids.permute(0, 2, 1, 3, 4).contiguous()           # [B,C,T,H,W] -> [B,T,C,H,W]
+        imgs = imgs.permute(0, 2, 1, 3, 4).contiguous()
+        pad = vids.new_zeros((vids.shape[0], vids.shape[1] - imgs.shape[1], *vids.shape[2:]))
+        imgs = torch.cat([imgs.to(vids.dtype), pad], dim=1)       # image latent in frame 0, zeros after (i2v.py:89-96)
+        import random
+        if random.random() < self.noised_image_dropout:           # conditional image dropout (i2v.py:98-99)
+            imgs = torch.zeros_like(imgs)
+        return {"videos": vids, "images": imgs, "prompt_embeds": emb}
+
+    def training_step(self, batch, batch_idx=0):
+        b = self.get_batch_input(batch)
+        x0 = b["videos"].to(torch.float32).contiguous()
+        B = x0.shape[0]
+        noise = torch.randn_like(x0)
+        timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=x0.device).long()
+        return self.loss_from(x0, b["prompt_embeds"], noise, timesteps, image_latents=b["images"].to(torch.float32))

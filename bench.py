@@ -152,6 +152,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ops.profile_collect()
     ops.profile_reset(False)
+    assert ops.attn_bwd_chain_errors() == 0, "a dQ hand-off wait of the attention backward timed out: results invalid"
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

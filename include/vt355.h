@@ -90,6 +90,10 @@ int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float
 
 /* Flash attention backward.  delta_ws: [B*H*S] fp32 workspace; dq_f32: fp32 [.., H*64] accumulation buffer
  * that the CALLER ZEROES beforehand (dQ is summed across key blocks with fp32 atomics); dk, dv bf16.
+ * chain_ws / chain_ws_bytes: optional scratch (256-byte aligned, >= vt_attn_bwd_chain_ws_bytes(B,H,S) bytes, contents
+ * don't matter) that lets runs of consecutive key blocks hand their running dQ tile to each other so that only one
+ * block per run issues atomics (csrc/attn_bwd.hip); NULL: every key block adds atomically.  ((int*)chain_ws)[8] is
+ * an error word: non-zero after the launch if a hand-off wait timed out (dQ is then invalid).
  * Replaces: autograd of the SDPA call above (loss.backward() under PL). */
 int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o, const void* dout,
                      const float* lse2, float* delta_ws, float* dq_f32, void* dk, void* dv,
@@ -98,7 +102,11 @@ int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o,
                      long long dq_rs, long long dk_rs, long long dv_rs,
                      long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
                      long long dq_bs, long long dk_bs, long long dv_bs,
-                     float softmax_scale, int q_prescaled, void* stream);
+                     float softmax_scale, int q_prescaled, void* chain_ws, long long chain_ws_bytes, void* stream);
+long long vt_attn_bwd_chain_ws_bytes(int B, int H, int S);
+/* tuning / test knob: chain_len 1 = atomics only, 0 = default (8, or VT_BWD_CHAIN); slots 0 = one workgroup per CU,
+ * else a smaller persistent grid (multiple of 8) so that small problems run several generations */
+int vt_attn_bwd_set_chain(int chain_len, int slots);
 
 /* y = LayerNorm(x; gamma, beta, eps) * (1 + scale[b,seg]) + shift[b,seg]; gamma/beta may be NULL (no
  * affine), the four modulation pointers may be NULL (plain LayerNorm).  mean/rstd [M] fp32 optional.

@@ -65,13 +65,15 @@ def test_attention_one_head_full_sequence(dev):
     # size-independent property: the softmax rows the kernel used sum to one  <=>  lse2 is consistent with O's scale
     dq = torch.zeros(1, S, 64, device=dev); dk = torch.empty(1, S, 64, dtype=BF, device=dev); dv = torch.empty_like(dk)
     delta = torch.empty(S, device=dev)
-    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(1, S, 64), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=True)
+    ws = ops.attn_bwd_chain_workspace(B, H, S, dev)
+    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(1, S, 64), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=True, chain_ws=ws)
+    assert ws is not None and ops.attn_bwd_chain_error(ws) == 0
     for name, got, ref in (("dq", dq[0], dq_ref), ("dk", dk[0], dk_ref), ("dv", dv[0], dv_ref)):
         l2, mx = relerr(got, ref)
         assert l2 < 1.5e-2 and mx < 5e-2, (name, l2, mx)
     # linearity of the backward in dO (size independent): bwd(2 dO) == 2 bwd(dO) up to bf16 rounding of the outputs
     dq2 = torch.zeros_like(dq); dk2 = torch.empty_like(dk); dv2 = torch.empty_like(dv)
-    ops.attn_bwd(qd, kd, vd, o, (2 * do).to(dev, BF).view(1, S, 64), lse2, delta, dq2, dk2, dv2, B, H, S, q_prescaled=True)
+    ops.attn_bwd(qd, kd, vd, o, (2 * do).to(dev, BF).view(1, S, 64), lse2, delta, dq2, dk2, dv2, B, H, S, q_prescaled=True)      # no workspace: plain atomics
     assert relerr(dq2, 2 * dq)[0] < 2e-3 and relerr(dv2.float(), 2 * dv.float())[0] < 8e-3
 
 

@@ -117,10 +117,21 @@ def test_attn_fwd(dev, B, S, H, spike, pre):
     close(lse2 * math.log(2.0), lse_ref, 1e-4, 2e-3, "lse")
 
 
+@pytest.mark.parametrize("chain", [0, 1, 2], ids=["atomics", "chains", "chains_3gen"])
 @pytest.mark.parametrize("pre", [False, True])
-@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 700, 2, False), (1, 256, 1, False)])
-def test_attn_bwd(dev, B, S, H, spike, pre):
+@pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 700, 2, False), (1, 256, 1, False),
+                                         (1, 3000, 2, False), (2, 2700, 3, True)])
+def test_attn_bwd(dev, B, S, H, spike, pre, chain):
+    """chain 0: one workgroup per key block, pure atomics.  chain 1: persistent grid, runs of consecutive key blocks
+    hand their dQ tiles to each other (12 / 11 key blocks per head in the two long cases: chains of up to 8, cut at
+    head ends and XCD slot-range ends).  chain 2: the same on a 24-slot grid -> several generations per slot, chains
+    of 3, slots that change role between generations."""
+    if S > 1000 and not pre:
+        pytest.skip("long cases run once (prescaled, the engine's configuration)")
+    if chain == 2 and S < 1000:
+        pytest.skip("multi-generation case needs more key blocks than slots")
     from vt355 import ops
+    ops.attn_bwd_set_chain(0, 24 if chain == 2 else 0)
     g = torch.Generator().manual_seed(S + 1)
     qkv = _qkv(B, S, H, g, spike)
     qkv, qkv_ref = _prescale(qkv, pre)
@@ -138,7 +149,14 @@ def test_attn_bwd(dev, B, S, H, spike, pre):
     dq = torch.zeros(B, S, D, dtype=torch.float32, device=dev)
     dk = torch.empty(B, S, D, dtype=BF, device=dev); dv = torch.empty(B, S, D, dtype=BF, device=dev)
     delta = torch.empty(B * H * S, dtype=torch.float32, device=dev)
-    ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(B, S, D), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=pre)
+    ws = ops.attn_bwd_chain_workspace(B, H, S, dev) if chain else None
+    assert (ws is not None) == bool(chain)
+    try:
+        ops.attn_bwd(qd, kd, vd, o, do.to(dev, BF).view(B, S, D), lse2, delta, dq, dk, dv, B, H, S, q_prescaled=pre, chain_ws=ws)
+        if chain:
+            assert ops.attn_bwd_chain_error(ws) == 0
+    finally:
+        ops.attn_bwd_set_chain(0, 0)
     scale = dref.abs().max().item()
     close(dq.view(B, S, H, 64), dref[:, :, 0], 3e-2, 1e-2 * scale, "dq")
     close(dk.view(B, S, H, 64), dref[:, :, 1], 3e-2, 1e-2 * scale, "dk")

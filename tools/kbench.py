@@ -60,7 +60,9 @@ def main():
         do = torch.randn(B, S, d, device=dev).to(BF)
         dq = torch.zeros(B, S, d, device=dev); dk = torch.empty(B, S, d, dtype=BF, device=dev); dv = torch.empty_like(dk)
         delta = torch.empty(B * H * S, device=dev)
-        med, mn = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S, q_prescaled=True), iters=5, warm=2)
+        ws = ops.attn_bwd_chain_workspace(B, H, S, dev)
+        med, mn = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S, q_prescaled=True, chain_ws=ws), iters=5, warm=2)
+        print('chain ws', None if ws is None else (ws.numel(), ops.attn_bwd_chain_error(ws)), 'VT_BWD_CHAIN', os.environ.get('VT_BWD_CHAIN'), flush=True)
         fl2 = 2.5 * fl
         res["attn_bwd"] = dict(ms=med, tflops_exec=fl2 / med / 1e9, tflops_alg=2 * fl / med / 1e9)
         print(f"attn bwd: {med:.3f} ms  {fl2/med/1e9:.0f} TF/s executed (5 products), {2*fl/med/1e9:.0f} algorithmic (min {mn:.3f})", flush=True)

@@ -33,7 +33,9 @@ PROTOTYPES = {
     "vt_silu_bwd": [_fp, _vp, _fp, _ll, _vp],
     "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
-                         _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
+                         _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp, _ll, _vp],
+    "vt_attn_bwd_chain_ws_bytes": [_i, _i, _i],
+    "vt_attn_bwd_set_chain": [_i, _i],
     "vt_ln_modulate_fwd": [_vp, _i, _vp, _i, _vp, _vp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _i, _f, _vp],
     "vt_ln_modulate_bwd": [_vp, _i, _vp, _i, _fp, _fp, _vp, _fp, _fp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "vt_qk_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _fp, _fp, _ll, _i, _f, _f, _fp, _fp, _i, _i, _vp],
@@ -55,7 +57,8 @@ PROTOTYPES = {
     "vt_lora_pack_b": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
     "vt_lora_pack_bt": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
 }
-_RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p, "vt_skinny_tn_workspace_bytes": C.c_longlong}
+_RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p, "vt_skinny_tn_workspace_bytes": C.c_longlong,
+             "vt_attn_bwd_chain_ws_bytes": C.c_longlong}
 
 
 def load_library():

@@ -18,7 +18,32 @@
 //     accumulator = two full 128-B row segments, the full-rate atomic shape).
 // All four LDS images (K block, dS, Q tile, dO tile) have 128-B rows and share one XOR swizzle that
 // is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
+//
+// Scheduling.  The kernel is PERSISTENT: one workgroup per CU ("slot"; 145 KiB of LDS allow exactly one), slot =
+// (XCD, index inside the XCD) under round-robin dispatch, each slot sweeping the key blocks slot, slot + G, slot + 2G ...
+// Consecutive key blocks of a head therefore run side by side on one XCD and stream the same Q / dO tiles through its
+// L2 at the same time (B=2, S=17776, H=30: 18.05 ms with one workgroup per key block -> 17.35 ms).
+//
+// dQ hand-off chains.  fp32 atomics execute memory-side at ~340 G lane-adds/s for the whole chip whatever the
+// locality or scope (tools/atomic_bench.hip: 1.36 TB/s of payload from 36 CUs up, the same from 256); adding every
+// key block's [S x 64] partial atomically is 7 ms of atomic-unit time per sample at S = 17776, and the kernel without
+// its atomics (results wrong, timing only) runs in 12.7 ms instead of 17.35.  With chain_len = L > 1, runs of up to L
+// consecutive key blocks of a head on consecutive slots of one XCD form a chain in every generation: block j hands its
+// running 64x64 fp32 dQ tile of every step to block j+1 through a ring of CH_R tiles in global memory (write-through
+// stores, cache-bypassing LDS-DMA loads, one ready and one consumed counter per wave, all counted in absolute steps
+// so nothing is reset between generations), block j+1 uses the tile as the initial accumulator of its own dQ MFMAs,
+// and only the last block of a chain issues atomics: ~L times fewer.  Counter loads and tile loads are issued a full
+// step before they are needed (one wave per SIMD: nothing hides a miss), so a consumer runs ~3 steps behind its
+// producer.  Every wait is bounded (CH_SPIN_LIMIT) and gives up with an error word instead of hanging.
+// What it buys (r01, B=2): L=2 16.6 ms, L=4 16.8, L=8 17.9-20 -- far from the 12.7 + 4.6/L the atomic count alone would
+// give, because the hand-off is itself vector-memory work on a one-wave-per-SIMD kernel: with all waits and all
+// atomics removed, the 4 tile stores cost +1.4 ms, the 4 DMA loads +0.8, counters and LDS reads +0.9 (vs 4.6 ms for the
+// 16 atomics they replace), and lock-stepping L blocks adds their stalls.  L = 2 is the default; L2-resident rings
+// (plain stores + agent-scope loads, 16.1 ms) were not adopted: they are only correct if chain neighbours really share
+// an XCD.  The roles are template parameters: with runtime flags the compiler's register allocation made the
+// atomic-only path of the same binary 26 % slower.
 #include "common.h"
+#include <cstdlib>
 
 // Experiment hooks: the same source can be compiled a second time under another symbol suffix / variant flags
 // (tools/build_variants.sh) so kernel variants are A/B-timed in ONE process.  The shipped build defines neither.
@@ -33,6 +58,9 @@
 #endif
 #ifndef VT_DQSHIFT
 #define VT_DQSHIFT 0   // 1 = the dQ MFMAs of step t-1 run inside step t VALU-bound slots (measured SLOWER: 11.5 vs 8.9 ms, the atomics then leave every wave in one burst right after the barrier)
+#endif
+#ifndef VT_CHAIN
+#define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
 #ifndef VT_ABL
 #define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write
@@ -58,6 +86,10 @@ struct AttnBwdParams {
     long long q_rs, k_rs, v_rs, do_rs, dq_rs, dk_rs, dv_rs;
     long long q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs;
     float scale, scale_log2;
+    int chain_len;        // 1: one workgroup per key block, every one adds its dQ partial atomically; > 1: persistent + chains
+    int* chain_ctr;       // [8] = error word                                    (zeroed by the host before the launch)
+    int* chain_flags;     // [slots][8]: ready[4 waves] | consumed[4 waves], in absolute steps (zeroed before the launch)
+    float* chain_tiles;   // [slots][CH_R][4 waves][4][64 lanes][4] fp32
 };
 
 #define KIMG 0
@@ -65,8 +97,32 @@ struct AttnBwdParams {
 #define QTILE 98304
 #define LSEOFF 131072
 #define BWD_LDS 132096
+#define CH_STAGE_BYTES 16384     // incoming dQ tile of the chain predecessor: 4 waves x 4 KiB, a separate LDS object so
+                                 // that the compiler does not order every ds_read of a step behind the DMA that fills it
+#ifndef CH_R
+#define CH_R 4                   // ring depth (tiles of 64 q x 64 d fp32 = 16 KiB)
+#endif
+#ifndef CH_HYST
+#define CH_HYST 1                // tiles of slack a consumer rebuilds whenever it had to wait for its producer
+#endif
+#define CH_SPIN_LIMIT (1 << 19)   // polls (~1 us each) before a wait gives up
+#define CH_AUX 17                // counters: sc0 | sc1 = system scope -- stores write through, loads bypass the caches
+#ifndef CH_ST_AUX
+#define CH_ST_AUX 17             // tile stores
+#endif
+#ifndef CH_LD_AUX
+#define CH_LD_AUX 17             // tile loads (LDS-DMA)
+#endif
+#if CH_LD_AUX == 17
+#define CH_LD_BITS "sc0 sc1"
+#elif CH_LD_AUX == 16
+#define CH_LD_BITS "sc1"
+#else
+#define CH_LD_BITS ""
+#endif
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
+typedef int i32x4w __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int swz_f(int row) {
     return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
@@ -81,12 +137,16 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v8);
 }
 
-template <bool RAGGED, bool PRESCALED>
-__device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
+// ROLE: bit 0 = has a chain predecessor (takes its running dQ tiles), bit 1 = has a successor (hands its tiles on instead of
+// adding them atomically).  A template parameter, not a runtime flag: each role gets its own register allocation -- with
+// runtime flags the atomic-only path of the same binary ran 26 % slower than the kernel without any chain code.
+template <bool RAGGED, bool PRESCALED, int ROLE>
+__device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, char* stage, const int id, const int slot,
+                                         const int cons_end, const int base, bool& dead) {
+    constexpr bool has_prod = (ROLE & 1) != 0, has_cons = (ROLE & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5, g = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
     const int nkb = (p.S + 255) / 256;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int kblk = id % nkb, bh = id / nkb;
     const int head = bh % p.H, b = bh / p.H;
     const int key0 = kblk * 256;
@@ -157,6 +217,36 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
     const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
     const int dq_rowb = (int)(p.dq_rs * 4);
 
+    // ---- dQ hand-off chain (see the header comment): has_prod / has_cons are workgroup-uniform ----
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 32u);
+    __amdgpu_buffer_rsrc_t rt_mine = make_rsrc(p.chain_tiles + (size_t)slot * (CH_R * 4096), CH_R * 16384);
+    const int fl_ready_me = (slot * 8 + wu) * 4, fl_cons_me = (slot * 8 + 4 + wu) * 4;
+    const int fl_ready_prod = ((slot - 1) * 8 + wu) * 4, fl_cons_next = ((slot + 1) * 8 + 4 + wu) * 4;
+    const int tile_voff = (wu * 256 + lane) * 16;          // + j * 1024, j = 0..3: registers 4j..4j+3 of the 32x32 dQ tile
+    const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+    i32x4w rt_prod_w;                                      // the predecessor's ring as raw descriptor words (inline asm operand)
+    {
+        const unsigned long long a = (unsigned long long)(p.chain_tiles + (size_t)(has_prod ? slot - 1 : slot) * (CH_R * 4096));
+        rt_prod_w = (i32x4w){(int)(unsigned)a, (int)((a >> 32) & 0xffffu), CH_R * 16384, 0x00020000};
+    }
+    // counter loads stay in a VGPR until the end-of-step barrier has waited for them anyway; only then are they moved to
+    // an SGPR (a readfirstlane anywhere else makes the compiler drain every outstanding memory operation on the spot)
+    auto fl_load = [&](int off) -> int { return (int)__builtin_amdgcn_raw_buffer_load_b32(rfl, off, 0, CH_AUX); };
+    int spins_r = 0, spins_c = 0;      // diagnostics: polls spent waiting for the predecessor / the successor
+    auto fl_wait = [&](int off, int need, int have, int& spins) {
+        int it = 0;
+#ifdef CH_NOWAIT            // timing-only ablation: never wait (results are wrong)
+        return;
+#endif
+        while (have < need && !dead) {
+            ++spins;
+            __builtin_amdgcn_s_sleep(4);
+            have = __builtin_amdgcn_readfirstlane(fl_load(off));
+            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; }
+        }
+    };
+
     // ---- staging of the Q / dO tiles (64 rows x 8 chunks each): 2 + 2 chunks per thread (branch free) ----
     int st_voq[2], st_vodo[2], st_lds[2];
 #pragma unroll
@@ -214,11 +304,38 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
     float dq_prev[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq_prev[i] = 0.f;
+    int pf_ready = 0;
+    if (has_prod) pf_ready = fl_load(fl_ready_prod);       // decides the tile-0 DMA; every later one is fetched a step ahead
     gload(0);
     lstore(0);
     __syncthreads();
+    int s_ready = has_prod ? __builtin_amdgcn_readfirstlane(pf_ready) : 0;
     for (int t = 0; t < nsteps; ++t) {
         const int buf = t & 1;
+        // chain traffic is issued a full step before its result is needed (one wave per SIMD: nothing hides a miss)
+        int pf_cons = 0;
+        if (has_prod) {
+            // predecessor's tile t must be public.  The counter at hand is a step old, and a consumer that passes with no
+            // margin is stopped again by the next hiccup of its producer, each time for a full uncached round trip that
+            // its own successors then inherit: when it does have to wait, it waits until the producer is CH_HYST tiles
+            // ahead, and then coasts on that slack.
+            if (s_ready < base + t + 1)
+                fl_wait(fl_ready_prod, base + (t + 1 + CH_HYST < nsteps ? t + 1 + CH_HYST : nsteps), s_ready, spins_r);
+            // LDS-DMA of the 4 x 1 KiB of this wave.  Issued through inline asm: the compiler orders every later LDS
+            // access of the step behind an LDS-DMA it knows about (s_waitcnt vmcnt(0) a few instructions into the step).
+            // Safe because these are the OLDEST memory operations of the step -- every wait the compiler computes for a
+            // younger load also covers them (vmcnt retires in order) -- and the end-of-step barrier drains the pipeline
+            // before the staging area is read.
+#ifndef CH_NODMA
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen " CH_LD_BITS " lds"
+                             :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                "s"(((base + t) % CH_R) * 16384) : "memory");
+#endif
+            pf_ready = fl_load(fl_ready_prod);                                             // for step t + 1
+        }
+        if (has_cons) pf_cons = fl_load(fl_cons_next);                                     // for the ring check at the end of this step
         gload(t + 1);                                  // past the end: bounds-checked loads return zeros
         const char* qimg = smem + QTILE + buf * 16384;
         const char* doimg = qimg + 8192;
@@ -447,6 +564,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
 #endif
         lstore(buf ^ 1);
         __syncthreads();
+        // the barrier drained the memory pipeline: the counters fetched at the top of the step are free to read now
+        if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);
+        const int s_cons = has_cons ? __builtin_amdgcn_readfirstlane(pf_cons) : 0;
 
 #if VT_ABL != 1
 #if VT_PIPE && VT_DQSHIFT
@@ -467,8 +587,18 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
 #else
         // ---- dQ tile (32 q x 32 d) of this wave over all 256 keys ----
         f32x16 dq_acc;
+        if (has_prod) {
+            // running sum of the chain so far (landed in LDS by the DMA issued mid-step; the barrier above waited for it)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = *(const f32x4*)(stage + wu * 4096 + j * 1024 + lane * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dq_acc[4 * j + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
+        }
         {
             // operands are fetched two k-steps ahead of the MFMA that consumes them (one wave per SIMD: nothing else
             // hides the LDS latency)
@@ -487,20 +617,53 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
                 dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s3 % 3], fb[s3 % 3], dq_acc, 0, 0, 0);
             }
         }
-        {
+        if (has_cons) {
+            // hand the running sum to the next key block.  Ring slot a % CH_R is free once its previous tile was consumed:
+            // tile a - CH_R, or -- in the first CH_R steps -- a tile of the last generation that had a successor
+            // (cons_end = absolute step count at the end of that generation, 0 if there was none).
+            const int a = base + t;
+            int need = a - CH_R + 1;
+            if (t < CH_R && need > cons_end) need = cons_end;
+            if (need > 0) fl_wait(fl_cons_next, need, s_cons, spins_c);
+            if (t > 0) {
+                // the stores of tile t-1 are a full step old: once acknowledged, tiles up to t-1 are public
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)a, rfl, fl_ready_me, 0, CH_AUX);
+            }
+#ifndef CH_NOST
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = {dq_acc[4 * j], dq_acc[4 * j + 1], dq_acc[4 * j + 2], dq_acc[4 * j + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024,
+                                                       (a % CH_R) * 16384, CH_ST_AUX);
+            }
+#else
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
+#endif
+        } else {
             const int soff = (int)((long long)(t) * 64 * p.dq_rs * 4);
 #if VT_ABL == 2
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
 #else
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq,
-                                                                dq_voff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, soff, 0);
+            for (int i = 0; i < 16; ++i)      // the row of register i goes into the scalar offset: one address VGPR, not 16
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff,
+                                                                soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
 #endif
         }
+        if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);   // tile t consumed
 #endif
 #endif
+    }
+    if ((has_prod || has_cons) && lane == 0 && (spins_r | spins_c)) {
+        if (spins_r) atomicAdd(p.chain_ctr + 9, spins_r);
+        if (spins_c) atomicAdd(p.chain_ctr + 10, spins_c);
+    }
+    if (has_cons) {     // the last tile
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + nsteps), rfl, fl_ready_me, 0, CH_AUX);
     }
 
 #if VT_PIPE && VT_DQSHIFT && VT_ABL != 1
@@ -534,9 +697,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
             for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
 #else
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq,
-                                                                dq_voff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, soff, 0);
+            for (int i = 0; i < 16; ++i)      // the row of register i goes into the scalar offset: one address VGPR, not 16
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff,
+                                                                soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
 #endif
         }
     }
@@ -568,10 +731,47 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem) {
 template <bool PRESCALED>
 __global__ __launch_bounds__(256, 1) void BWD_KERNEL(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[BWD_LDS];
+    __shared__ __attribute__((aligned(16))) char stage[CH_STAGE_BYTES];
     const int nkb = (p.S + 255) / 256;
-    const int kblk = xcd_remap(blockIdx.x, gridDim.x) % nkb;
-    if ((kblk + 1) * 256 > p.S) BWD_BODY<true, PRESCALED>(p, smem);   // block-uniform: only the last key block is ragged
-    else BWD_BODY<false, PRESCALED>(p, smem);
+    const int nitems = nkb * p.H * p.B, nsteps = (p.S + 63) / 64;
+    const int L = p.chain_len;
+    // persistent grid: slot = (XCD, index inside the XCD) under round-robin dispatch; consecutive slots share an XCD, and
+    // a slot sweeps the key blocks slot, slot + G, ...  (consecutive key blocks of a head run side by side on one XCD and
+    // stream the same Q / dO tiles through its L2 at the same time)
+    const int spx = gridDim.x >> 3;
+    const int slot = (int)(blockIdx.x & 7) * spx + (int)(blockIdx.x >> 3);
+    bool dead = false;
+    int cons_end = 0;
+    int gen = 0;
+    for (int item = slot; item < nitems; item += gridDim.x, ++gen) {
+        const int kblk = item % nkb;
+        bool has_prod = false, has_cons = false;
+#if VT_CHAIN
+        if (L > 1) {
+            const int j = slot % spx;         // chains: same head, same XCD, at most L long, aligned to multiples of L
+            has_prod = (j % L) != 0 && kblk != 0;
+            has_cons = (j % L) != L - 1 && j != spx - 1 && kblk != nkb - 1 && item + 1 < nitems;
+        }
+#endif
+        // block-uniform: only the last key block of a head is ragged
+        const bool ragged = (kblk + 1) * 256 > p.S;
+        const int role = (has_prod ? 1 : 0) | (has_cons ? 2 : 0);
+        const int base = gen * nsteps;
+#define VT_BWD_CALL(R, ROLE_) BWD_BODY<R, PRESCALED, ROLE_>(p, smem, stage, item, slot, cons_end, base, dead)
+#if VT_CHAIN
+        switch (role) {
+            case 0: if (ragged) VT_BWD_CALL(true, 0); else VT_BWD_CALL(false, 0); break;
+            case 1: if (ragged) VT_BWD_CALL(true, 1); else VT_BWD_CALL(false, 1); break;     // a ragged block ends its head: never a producer
+            case 2: VT_BWD_CALL(false, 2); break;
+            default: VT_BWD_CALL(false, 3); break;
+        }
+#else
+        if (ragged) VT_BWD_CALL(true, 0); else VT_BWD_CALL(false, 0);
+#endif
+#undef VT_BWD_CALL
+        if (has_cons) cons_end = (gen + 1) * nsteps;
+        __syncthreads();                      // the LDS images are rebuilt by the next item
+    }
 }
 
 // delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (8 lanes per (s,h) row of 64 elements)
@@ -607,6 +807,37 @@ __global__ __launch_bounds__(256) void DELTA_KERNEL(const bf16_t* o, const bf16_
     }
 }
 
+// workspace layout: [0,64) tickets + error word | [256, 256 + 32 nwg) counters | tiles from the next 4 KiB boundary
+static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 32 + 4095) & ~4095LL; }
+static long long bwd_chain_ws_bytes(long long slots) { return bwd_chain_tiles_off(slots) + slots * (long long)(CH_R * 16384); }
+static int g_bwd_slots = 0;      // persistent grid: one workgroup per CU, a multiple of 8
+// chain length: VT_BWD_CHAIN (1 = off), default 2 (measured best: see the header comment).  The persistent grid is one workgroup per CU (the kernel's 145 KiB
+// of LDS allow exactly one), so every slot is resident and chain neighbours start together.
+static int g_bwd_chain = -1;
+static void bwd_chain_init() {
+    if (g_bwd_chain >= 0) return;
+    int L = 2;
+    if (const char* e = getenv("VT_BWD_CHAIN")) L = atoi(e);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    g_bwd_slots = cus / 8 * 8;
+    if (g_bwd_slots < 8) g_bwd_slots = 8;
+    g_bwd_chain = L < 1 ? 1 : L;
+}
+static int bwd_chain_len() { bwd_chain_init(); return g_bwd_chain; }
+// tuning / test knob: chain_len 1 = atomics only, 0 = default; slots 0 = one per CU, else a smaller persistent grid
+// (multiple of 8, never more than the CU count) so that small problems run several generations
+extern "C" int VT_CAT(vt_attn_bwd_set_chain, VT_SUFFIX)(int chain_len, int slots) {
+    g_bwd_chain = -1;
+    bwd_chain_init();
+    if (chain_len > 0) g_bwd_chain = chain_len;
+    if (slots > 0) {
+        if ((slots % 8) || slots > g_bwd_slots) return VT_ERR_BAD_SHAPE;
+        g_bwd_slots = slots;
+    }
+    return VT_OK;
+}
+
 extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void* o, const void* dout,
                                 const float* lse2, float* delta_ws, float* dq_f32, void* dk, void* dv,
                                 int B, int H, int S,
@@ -614,7 +845,8 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
                                 long long dq_rs, long long dk_rs, long long dv_rs,
                                 long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
                                 long long dq_bs, long long dk_bs, long long dv_bs,
-                                float softmax_scale, int q_prescaled, void* stream) {
+                                float softmax_scale, int q_prescaled, void* chain_ws, long long chain_ws_bytes,
+                                void* stream) {
     if (B <= 0 || H <= 0 || S <= 0) return VT_ERR_BAD_SHAPE;
     if ((long long)S * dq_rs * 4 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 8) || (do_rs % 8) || (dk_rs % 4) || (dv_rs % 4)) return VT_ERR_BAD_SHAPE;
@@ -639,7 +871,33 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.do_bs = do_bs; p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs;
     p.scale = softmax_scale; p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const int nkb = (S + 255) / 256;
-    if (q_prescaled) hipLaunchKernelGGL(BWD_KERNEL<true>, dim3(nkb * H * B), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(BWD_KERNEL<false>, dim3(nkb * H * B), dim3(256), 0, st, p);
+    const long long nwg = (long long)nkb * H * B;
+    if (nwg > 0x3fffffLL) return VT_ERR_BAD_SHAPE;
+    // dQ hand-off chains: need the caller's workspace and enough co-resident workgroups per XCD (see the header comment)
+    p.chain_len = 1; p.chain_ctr = nullptr; p.chain_flags = nullptr; p.chain_tiles = nullptr;
+    int L = bwd_chain_len();
+    const long long pgrid = nwg < g_bwd_slots ? (nwg + 7) / 8 * 8 : g_bwd_slots;      // persistent grid, a multiple of 8
+    const long long grid = pgrid;
+    if (L > pgrid / 8) L = (int)(pgrid / 8);
+    if (L > nkb) L = nkb;
+    if (chain_ws != nullptr && chain_ws_bytes >= 64 && !(((uintptr_t)chain_ws) & 255)) {
+        char* ws = (char*)chain_ws;
+        const bool on = L > 1 && chain_ws_bytes >= bwd_chain_ws_bytes(g_bwd_slots);
+        if (hipMemsetAsync(ws, 0, on ? (size_t)bwd_chain_tiles_off(g_bwd_slots) : 64, st) != hipSuccess) return VT_ERR_LAUNCH;
+        if (on) {
+            p.chain_len = L;
+            p.chain_ctr = (int*)ws;
+            p.chain_flags = (int*)(ws + 256);
+            p.chain_tiles = (float*)(ws + bwd_chain_tiles_off(g_bwd_slots));
+        }
+    }
+    if (q_prescaled) hipLaunchKernelGGL(BWD_KERNEL<true>, dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(BWD_KERNEL<false>, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// bytes of chain workspace vt_attn_bwd_hd64 wants for this problem (0: chains are disabled on this device / by VT_BWD_CHAIN=1)
+extern "C" long long VT_CAT(vt_attn_bwd_chain_ws_bytes, VT_SUFFIX)(int B, int H, int S) {
+    if (B <= 0 || H <= 0 || S <= 0 || bwd_chain_len() <= 1) return 0;
+    return bwd_chain_ws_bytes(g_bwd_slots);
 }

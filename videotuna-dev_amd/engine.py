@@ -277,6 +277,7 @@ def run_backward(model, ctx, dout: torch.Tensor):
     dqkv = E(M, 3 * d)
     dx1 = E(M, d + EXT)
     delta = E(B * H * S, dt=torch.float32)
+    chain_ws = ops.attn_bwd_chain_workspace(B, H, S, dev)
     dh_in = E(M, d)
     for i in reversed(range(L)):
         Lw, a = P.layers[i], ctx.blocks[i]
@@ -296,7 +297,7 @@ def run_backward(model, ctx, dout: torch.Tensor):
         qk3, qkv3 = a.qkh.view(B, S, 2 * d), a.qkv.view(B, S, 3 * d)
         ops.attn_bwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], a.o.view(B, S, d + EXT)[:, :, :d],
                      dO.view(B, S, d + EXT)[:, :, :d], a.lse, delta, dq, dkh.view(B, S, d),
-                     dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S, q_prescaled=True)
+                     dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S, q_prescaled=True, chain_ws=chain_ws)
         ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H, rope=ctx.rope)
         ops.gemm(dqkv, Lw.w_qkv_t, dx1, None)                             # [M, d+EXT]: dx1 | dT1
         for j in range(3):

@@ -101,6 +101,11 @@ def run_backward_fullft(model, ctx, dout: torch.Tensor, on_grads_ready: Optional
     tg = E(M, d); du = E(M, c.ff_mult * d); dx2 = E(M, d); dh1 = E(M, d); dO = E(M, d)
     dq = E(B, S, d, dt=F32); dkh = E(M, d); dqkv = E(M, 3 * d); dx1 = E(M, d)
     delta = E(B * H * S, dt=F32); dh_in = E(M, d)
+    # dQ hand-off chains need every persistent workgroup resident: not while RCCL kernels of the overlapped gradient
+    # all-reduce share the CUs (on_grads_ready set) -- then the kernel runs persistent with plain atomics
+    reducer = getattr(on_grads_ready, "__self__", None)
+    overlapped = on_grads_ready is not None and getattr(reducer, "world", 2) > 1
+    chain_ws = None if overlapped else ops.attn_bwd_chain_workspace(B, H, S, dev)
     for i in reversed(range(L)):
         Lw, a = P.layers[i], ctx.blocks[i]
         pre = f"transformer_blocks.{i}."
@@ -129,7 +134,7 @@ def run_backward_fullft(model, ctx, dout: torch.Tensor, on_grads_ready: Optional
         qk3, qkv3 = a.qkh.view(B, S, 2 * d), a.qkv.view(B, S, 3 * d)
         ops.attn_bwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], a.o.view(B, S, a.o.shape[1])[:, :, :d],
                      dO.view(B, S, d), a.lse, delta, dq, dkh.view(B, S, d), dqkv.view(B, S, 3 * d)[:, :, 2 * d:], B, H, S,
-                     q_prescaled=True)
+                     q_prescaled=True, chain_ws=chain_ws)
         # q/k LayerNorm parameters: the four 64-vectors are adjacent in the flat layout -> written in place
         ops.qk_ln_param_grads(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, g(pre + "attn1.norm_q.weight"), H, rope=ctx.rope)
         ops.qk_layernorm_bwd(dq.view(M, d), dkh, a.qkv, a.qmean, a.qrstd, Lw.gq, Lw.gk, dqkv, H, rope=ctx.rope)

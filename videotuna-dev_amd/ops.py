@@ -177,8 +177,39 @@ def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = 
           "vt_attn_fwd_hd64")
 
 
+def attn_bwd_chain_workspace(B: int, H: int, S: int, device) -> Optional[torch.Tensor]:
+    """scratch for the dQ hand-off chains of vt_attn_bwd_hd64 (None when the library runs without chains); one buffer
+    serves every attention-backward launch of a step"""
+    n = int(load_library().vt_attn_bwd_chain_ws_bytes(B, H, S))
+    if n <= 0:
+        return None
+    key = str(device)
+    ws = _CHAIN_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _CHAIN_WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return ws
+
+
+_CHAIN_WS = {}      # device -> workspace, reused by every launch on that device (launches of one stream are ordered)
+
+
+def attn_bwd_chain_errors() -> int:
+    """error words of every chain workspace handed out so far (synchronises); non-zero = a dQ hand-off wait timed out"""
+    return sum(attn_bwd_chain_error(ws) for ws in _CHAIN_WS.values())
+
+
+def attn_bwd_set_chain(chain_len: int = 0, slots: int = 0):
+    """tuning / test knob of the dQ hand-off chains (0 = defaults); see include/vt355.h"""
+    check(load_library().vt_attn_bwd_set_chain(chain_len, slots), "vt_attn_bwd_set_chain")
+
+
+def attn_bwd_chain_error(chain_ws: torch.Tensor) -> int:
+    """error word of the last launch that used this workspace (synchronises): non-zero = a hand-off wait timed out"""
+    return int(chain_ws[32:36].view(torch.int32).item())
+
+
 def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: int, scale: Optional[float] = None,
-             q_prescaled: bool = False):
+             q_prescaled: bool = False, chain_ws: Optional[torch.Tensor] = None):
     scale = 1.0 / math.sqrt(64) if scale is None else scale
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dk", dk), ("dv", dv)):
         _req(t, BF16, n, 3)
@@ -191,7 +222,9 @@ def attn_bwd(q, k, v, o, do, lse2, delta_ws, dq_f32, dk, dv, B: int, H: int, S: 
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1),
                                dq_f32.stride(1), dk.stride(1), dv.stride(1),
                                q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
-                               dq_f32.stride(0), dk.stride(0), dv.stride(0), scale, int(q_prescaled), _stream()),
+                               dq_f32.stride(0), dk.stride(0), dv.stride(0), scale, int(q_prescaled),
+                               None if chain_ws is None else chain_ws.data_ptr(), 0 if chain_ws is None else chain_ws.numel(),
+                               _stream()),
           "vt_attn_bwd_hd64")
 
 

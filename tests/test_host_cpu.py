@@ -205,3 +205,77 @@ def test_cogvideox_5b_rope_host_side(tmp_path):
     assert torch.equal(m2.patch_embed.pos_embedding, table)
     with pytest.raises(ValueError):
         CogVideoXTransformer3DModel(use_learned_positional_embeddings=True, num_layers=1)
+
+
+def test_checkpoint_io_reference_conventions(tmp_path):
+    """PL-style .ckpt written through the workflow's LoRA-only filter (cogvideo_pl.py:781-787), the reference's strict
+    LoRA loader (lvdm/ddpm3d.py:406-432) and auto-resume path selection (utils/train_utils.py:251-288)."""
+    from types import SimpleNamespace
+    from vt355 import checkpoint as C
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.lora import LoraConfig, get_peft_model
+    from vt355.workflow import CogVideoXWorkFlow
+
+    def tiny_peft(seed):
+        m = CogVideoXTransformer3DModel(num_layers=1, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64).init_weights(seed)
+        m.requires_grad_(False)
+        return get_peft_model(m, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
+    src = tiny_peft(0)
+    with torch.no_grad():
+        for n, p in src.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape) * 0.01)
+    wf = SimpleNamespace(model=src, global_step=37)
+    wf.on_save_checkpoint = lambda ck: CogVideoXWorkFlow.on_save_checkpoint(wf, ck)
+    path = C.save_checkpoint(wf, str(tmp_path / "run" / "checkpoints" / "last.ckpt"), epoch=3)
+    ck = C.load_checkpoint_file(path)                       # weights_only=True
+    assert ck["epoch"] == 3 and ck["global_step"] == 37
+    assert len(ck["state_dict"]) == 8 and all(k.startswith("model.base_model.model.") and "lora" in k for k in ck["state_dict"])
+    dst = tiny_peft(1)
+    assert C.load_lora_from_ckpt(dst, path) == 8
+    for (n, a), (_, b) in zip(src.named_parameters(), dst.named_parameters()):
+        if "lora" in n:
+            assert torch.equal(a, b), n
+    # strict both ways
+    extra = dict(ck); extra["state_dict"] = dict(ck["state_dict"], **{"model.base_model.model.bogus.lora_A.default.weight": torch.zeros(4, 4)})
+    torch.save(extra, tmp_path / "extra.ckpt")
+    with pytest.raises(RuntimeError, match="was not copied"):
+        C.load_lora_from_ckpt(tiny_peft(2), str(tmp_path / "extra.ckpt"))
+    fewer = dict(ck); fewer["state_dict"] = {k: v for i, (k, v) in enumerate(ck["state_dict"].items()) if i}
+    torch.save(fewer, tmp_path / "fewer.ckpt")
+    with pytest.raises(RuntimeError, match="not found"):
+        C.load_lora_from_ckpt(tiny_peft(2), str(tmp_path / "fewer.ckpt"))
+    # auto-resume: last.ckpt when readable, else the newest other checkpoint, None without a checkpoints dir
+    assert C.get_autoresume_path(str(tmp_path / "run")) == path
+    assert C.get_autoresume_path(str(tmp_path / "nothing")) is None
+    C.save_checkpoint(wf, str(tmp_path / "run" / "checkpoints" / "epoch=0002.ckpt"), epoch=2)
+    (tmp_path / "run" / "checkpoints" / "last.ckpt").write_bytes(b"truncated")
+    assert C.get_autoresume_path(str(tmp_path / "run")).endswith("epoch=0002.ckpt")
+    # full-state round trip (full fine-tune recipes keep every weight: no 'lora' key -> nothing filtered)
+    base = CogVideoXTransformer3DModel(num_layers=1, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64).init_weights(4)
+    wf2 = SimpleNamespace(model=base, global_step=5)
+    wf2.on_save_checkpoint = lambda ck: CogVideoXWorkFlow.on_save_checkpoint(wf2, ck)
+    p2 = C.save_checkpoint(wf2, str(tmp_path / "full.ckpt"))
+    other = CogVideoXTransformer3DModel(num_layers=1, num_attention_heads=2, time_embed_dim=64, text_embed_dim=64).init_weights(9)
+    wf3 = SimpleNamespace(model=other, global_step=0)
+    C.load_full_checkpoint(wf3, p2)
+    assert wf3.global_step == 5 and all(torch.equal(a, b) for a, b in zip(base.state_dict().values(), other.state_dict().values()))
+
+
+def test_encoder_prefetcher_sequencing():
+    """vt355.prefetch: batches come out in order, each encoded exactly once, `depth` batches ahead of the consumer."""
+    from vt355.prefetch import EncoderPrefetcher
+    log = []
+
+    def encode(raw):
+        log.append(("enc", raw["i"]))
+        return {"latents": torch.full((2, 3), float(raw["i"])), "prompt_embeds": [torch.ones(1) * raw["i"]]}
+    got = []
+    for b in EncoderPrefetcher(({"i": i} for i in range(5)), encode, device="cpu", depth=2):
+        log.append(("use", int(b["latents"][0, 0])))
+        got.append(int(b["prompt_embeds"][0]))
+    assert got == [0, 1, 2, 3, 4]
+    assert log[:4] == [("enc", 0), ("enc", 1), ("enc", 2), ("use", 0)]          # two batches ahead
+    assert [x for x in log if x[0] == "enc"] == [("enc", i) for i in range(5)]
+    with pytest.raises(ValueError):
+        EncoderPrefetcher([], encode, depth=0)

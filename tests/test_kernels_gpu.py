@@ -28,8 +28,18 @@ def close(a, b, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 1984, 1920), (129, 128, 64), (2, 1536, 512), (17776, 1920, 1984)])
-def test_gemm_bias(dev, M, N, K):
+@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+def gemm_tile(request):
+    """both tilings of vt_gemm_bf16 (the library picks by shape; the tests force each one on every shape)"""
+    from vt355 import ops
+    ops.gemm_set_tile(request.param)
+    yield request.param
+    ops.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 1984, 1920), (129, 128, 64), (2, 1536, 512), (17776, 1920, 1984),
+                                   (513, 772, 192)])
+def test_gemm_bias(dev, M, N, K, gemm_tile):
     from vt355 import ops
     g = torch.Generator().manual_seed(M + N + K)
     a = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) * 0.05); b = rb(torch.randn(N, generator=g))
@@ -42,10 +52,11 @@ def test_gemm_bias(dev, M, N, K):
     close(out32, ref, 1e-4, 2e-3, "gemm fp32 out")
 
 
-def test_gemm_strided_and_epilogues(dev):
+@pytest.mark.parametrize("N", [256, 388])
+def test_gemm_strided_and_epilogues(dev, gemm_tile, N):
     from vt355 import ops
     g = torch.Generator().manual_seed(7)
-    B, S, St, K, N = 2, 150, 20, 128, 256
+    B, S, St, K = 2, 150, 20, 128
     M = B * S
     abig = rb(torch.randn(M, K + 64, generator=g))            # lda > K (extension columns ignored via K=)
     w = rb(torch.randn(N, K, generator=g) * 0.1); bias = rb(torch.randn(N, generator=g))

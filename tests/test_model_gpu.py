@@ -167,3 +167,29 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev, variant):
     # the packed transposed operands follow the new weights at the next forward
     out2 = fwd()
     assert torch.isfinite(out2.float()).all() and not torch.equal(out2, out)
+
+
+def test_encoder_prefetcher_overlaps_on_a_side_stream(dev):
+    """SURVEY 8(f) rank 1 plumbing: stand-in 'frozen encoders' (a few matmuls) run on the prefetcher's side stream while the
+    main stream is busy; every batch arrives complete, in order, and identical to encoding it synchronously."""
+    from vt355.prefetch import EncoderPrefetcher
+    g = torch.Generator().manual_seed(3)
+    w1 = torch.randn(512, 512, generator=g).to(dev)
+    raws = [{"video": torch.randn(4, 512, 512, generator=g), "i": i} for i in range(6)]
+
+    def encode(raw):
+        x = raw["video"].to(dev, non_blocking=True)
+        for _ in range(8):
+            x = torch.tanh(x @ w1 * 0.05)
+        return {"latents": x, "prompt_embeds": x.sum(dim=-1), "i": raw["i"]}
+    with torch.no_grad():
+        want = [encode(r)["latents"].clone() for r in raws]
+    torch.cuda.synchronize()
+    busy = torch.randn(4096, 4096, device=dev)
+    pf = EncoderPrefetcher(raws, encode, device=dev, depth=2)
+    assert pf.side is not None and pf.side != torch.cuda.current_stream(dev)
+    for k, b in enumerate(pf):
+        busy = busy @ busy * 1e-3                   # main-stream work the side stream overlaps with
+        assert b["i"] == k
+        assert torch.equal(b["latents"], want[k])   # consumed on the main stream after the event wait
+    torch.cuda.synchronize()

@@ -28,14 +28,18 @@ def main():
     S, H, d = 17776, 30, 1920
     res = {}
     if "gemm" in which:
-        for (M, N, K, name) in [(S, 5760, 1984, "qkv"), (S, 1920, 1984, "out"), (S, 7680, 1920, "ff1"), (S, 1920, 7680, "ff2"),
+        for (M, N, K, name) in [(2 * S, 5760, 1984, "qkv2"), (2 * S, 1920, 1984, "out2"), (2 * S, 7680, 1920, "ff1_2"), (2 * S, 1920, 7680, "ff2_2"), (2 * S, 1984, 5760, "dqkv2"), (2 * S, 1984, 1920, "dout2"),
+                                (S, 5760, 1984, "qkv"), (S, 1920, 1984, "out"), (S, 7680, 1920, "ff1"), (S, 1920, 7680, "ff2"),
                                 (S, 1984, 5760, "dqkv"), (4096, 4096, 4096, "sq4k"), (8192, 8192, 8192, "sq8k")]:
             a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
             out = torch.empty(M, N, dtype=BF, device=dev); b = torch.zeros(N, dtype=BF, device=dev)
-            med, mn = timeit(lambda: ops.gemm(a, w, out, b))
-            tf = 2.0 * M * N * K / med / 1e9
-            res["gemm_" + name] = dict(ms=med, tflops=tf)
-            print(f"gemm {name:5s} M={M} N={N} K={K}: {med:.3f} ms  {tf:.0f} TF/s (min {mn:.3f})", flush=True)
+            for mode, tag in ((1, "tile128"), (2, "tile256")):
+                ops.gemm_set_tile(mode)
+                med, mn = timeit(lambda: ops.gemm(a, w, out, b))
+                tf = 2.0 * M * N * K / med / 1e9
+                res["gemm_" + name + "_" + tag] = dict(ms=med, tflops=tf)
+                print(f"gemm {name:5s} {tag} M={M} N={N} K={K}: {med:.3f} ms  {tf:.0f} TF/s (min {mn:.3f})", flush=True)
+            ops.gemm_set_tile(0)
             if name == "ff1":
                 pre = torch.empty(M, N, dtype=BF, device=dev)
                 med, mn = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))

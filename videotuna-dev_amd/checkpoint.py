@@ -1,0 +1,110 @@
+"""Checkpoint I/O in the reference's on-disk conventions -- host-side plumbing, no kernels.
+
+* ``save_checkpoint`` writes what PL's ModelCheckpoint would for the workflow: ``{"state_dict": {"model.<key>": tensor},
+  "epoch", "global_step", "optimizer_states": [...]}``, after the workflow's own ``on_save_checkpoint`` (LoRA-only filter,
+  videotuna/models/cogvideo_hf/cogvideo_pl.py:781-787; same rule as LoraModelCheckpoint, videotuna/utils/callbacks.py:28-53).
+* ``load_lora_from_ckpt`` restates videotuna/models/lvdm/ddpm3d.py:406-432: every ``lora`` parameter of the model must be
+  in the file under ``model.<name>`` AND every key of the file must be consumed exactly once -- anything else raises.
+* ``get_autoresume_path`` restates videotuna/utils/train_utils.py:251-288 (last.ckpt, else the newest other file).
+
+Files are read with ``torch.load(weights_only=True)`` only.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional
+
+import torch
+
+
+def checkpoint_dict(workflow, optimizer=None, epoch: int = 0, global_step: Optional[int] = None) -> Dict[str, Any]:
+    sd = {"model." + k: v.detach().to("cpu").clone() for k, v in workflow.model.state_dict().items()}
+    ck: Dict[str, Any] = {"state_dict": sd, "epoch": int(epoch),
+                          "global_step": int(workflow.global_step if global_step is None else global_step)}
+    if optimizer is not None:
+        ck["optimizer_states"] = [optimizer.state_dict()]
+    return workflow.on_save_checkpoint(ck)
+
+
+def save_checkpoint(workflow, path: str, optimizer=None, epoch: int = 0, global_step: Optional[int] = None) -> str:
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = path + ".tmp"
+    torch.save(checkpoint_dict(workflow, optimizer, epoch, global_step), tmp)
+    os.replace(tmp, path)          # a crash never leaves a truncated last.ckpt behind
+    return path
+
+
+def load_checkpoint_file(path: str) -> Dict[str, Any]:
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_lora_from_ckpt(model, path: str, verbose: bool = False) -> int:
+    """strict both ways (ddpm3d.py:406-432); returns the number of tensors copied"""
+    lora_state_dict = load_checkpoint_file(path)["state_dict"]
+    copied = {k: False for k in lora_state_dict}
+    for n, p in model.named_parameters():
+        if "lora" not in n:
+            continue
+        key = f"model.{n}"
+        if key not in lora_state_dict:
+            raise RuntimeError(f"Parameter {key} not found in lora_state_dict.")
+        if copied[key]:
+            raise RuntimeError(f"Parameter {key} has already been copied once.")
+        src = lora_state_dict[key]
+        if tuple(src.shape) != tuple(p.shape):
+            raise RuntimeError(f"Parameter {key}: shape {tuple(src.shape)} in the file, {tuple(p.shape)} in the model.")
+        with torch.no_grad():
+            p.copy_(src.to(device=p.device, dtype=p.dtype))
+        copied[key] = True
+        if verbose:
+            print(f"Copying parameter {key}")
+    for key, ok in copied.items():
+        if not ok:
+            raise RuntimeError(f"Parameter {key} from lora_state_dict was not copied to the model.")
+    st = getattr(model, "_lora_state", None)
+    if st is not None:
+        st.mark_changed()             # the engine's packed [W | B] operands follow the new adapters
+    return len(copied)
+
+
+def load_full_checkpoint(workflow, path: str, optimizer=None, strict: bool = True) -> Dict[str, Any]:
+    """resume a full-state checkpoint written by save_checkpoint (full fine-tune: every weight is in the file)"""
+    ck = load_checkpoint_file(path)
+    sd = {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+    target = workflow.model.state_dict()
+    missing = [k for k in target if k not in sd]
+    unexpected = [k for k in sd if k not in target]
+    if strict and (missing or unexpected):
+        raise RuntimeError(f"checkpoint does not match the model: missing {missing[:4]}..., unexpected {unexpected[:4]}...")
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k in target:
+                target[k].copy_(v.to(device=target[k].device, dtype=target[k].dtype))
+    ft = getattr(workflow.model, "fullft", None)
+    if ft is not None:                # fp32 master follows the loaded bf16 weights
+        ft.flat.copy_(ft.flat_bf16)
+        ft.mark_changed()
+    st = getattr(workflow.model, "_lora_state", None)
+    if st is not None:
+        st.mark_changed()
+    if optimizer is not None and ck.get("optimizer_states"):
+        optimizer.load_state_dict(ck["optimizer_states"][0])
+    workflow.global_step = int(ck.get("global_step", 0))
+    return ck
+
+
+def get_autoresume_path(logdir: str) -> Optional[str]:
+    ckdir = os.path.join(logdir, "checkpoints")
+    ckpt = os.path.join(ckdir, "last.ckpt")
+    if not os.path.exists(ckpt):
+        return None
+    try:
+        tmp = load_checkpoint_file(ckpt)
+        _ = tmp["epoch"], tmp["global_step"]
+        return ckpt
+    except Exception:
+        others = sorted(f for f in os.listdir(ckdir) if not os.path.isdir(os.path.join(ckdir, f)))
+        others = [f for f in others if f not in ("last.ckpt", "trainstep_checkpoints")]
+        if not others:
+            return ckpt           # the reference returns last.ckpt here too and lets the loader fail loudly
+        return os.path.join(ckdir, others[-1])

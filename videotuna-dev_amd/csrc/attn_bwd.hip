@@ -89,6 +89,7 @@ struct AttnBwdParams {
     int chain_len;        // 1: one workgroup per key block, every one adds its dQ partial atomically; > 1: persistent + chains
     int* chain_ctr;       // [8] = error word                                    (zeroed by the host before the launch)
     int* chain_flags;     // [slots][8]: ready[4 waves] | consumed[4 waves], in absolute steps (zeroed before the launch)
+    int* chain_xcc;       // [slots] 1 + XCC_ID of the workgroup that runs the slot (0 = not started yet; zeroed before the launch)
     float* chain_tiles;   // [slots][CH_R][4 waves][4][64 lanes][4] fp32
 };
 
@@ -107,19 +108,6 @@ struct AttnBwdParams {
 #endif
 #define CH_SPIN_LIMIT (1 << 19)   // polls (~1 us each) before a wait gives up
 #define CH_AUX 17                // counters: sc0 | sc1 = system scope -- stores write through, loads bypass the caches
-#ifndef CH_ST_AUX
-#define CH_ST_AUX 17             // tile stores
-#endif
-#ifndef CH_LD_AUX
-#define CH_LD_AUX 17             // tile loads (LDS-DMA)
-#endif
-#if CH_LD_AUX == 17
-#define CH_LD_BITS "sc0 sc1"
-#elif CH_LD_AUX == 16
-#define CH_LD_BITS "sc1"
-#else
-#define CH_LD_BITS ""
-#endif
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
 typedef int i32x4w __attribute__((ext_vector_type(4)));
@@ -142,7 +130,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 // runtime flags the atomic-only path of the same binary ran 26 % slower than the kernel without any chain code.
 template <bool RAGGED, bool PRESCALED, int ROLE>
 __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, char* stage, const int id, const int slot,
-                                         const int cons_end, const int base, bool& dead) {
+                                         const int cons_end, const int base, const bool l2_prev, const bool l2_next,
+                                         bool& dead) {
     constexpr bool has_prod = (ROLE & 1) != 0, has_cons = (ROLE & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5, g = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
@@ -327,11 +316,21 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             // younger load also covers them (vmcnt retires in order) -- and the end-of-step barrier drains the pipeline
             // before the staging area is read.
 #ifndef CH_NODMA
+            // cache policy: the predecessor shares this XCD's L2 (l2_prev: its plain stores are there) -> agent-scope
+            // load, L1 bypassed; otherwise system scope against its write-through stores
+            if (l2_prev) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen " CH_LD_BITS " lds"
-                             :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
-                                "s"(((base + t) % CH_R) * 16384) : "memory");
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds"
+                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+            }
 #endif
             pf_ready = fl_load(fl_ready_prod);                                             // for step t + 1
         }
@@ -634,8 +633,13 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 v = {dq_acc[4 * j], dq_acc[4 * j + 1], dq_acc[4 * j + 2], dq_acc[4 * j + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024,
-                                                       (a % CH_R) * 16384, CH_ST_AUX);
+                // successor on this XCD: the tile only has to reach the shared L2; otherwise write through to memory
+                if (l2_next)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024,
+                                                           (a % CH_R) * 16384, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024,
+                                                           (a % CH_R) * 16384, CH_AUX);
             }
 #else
 #pragma unroll
@@ -743,6 +747,33 @@ __global__ __launch_bounds__(256, 1) void BWD_KERNEL(AttnBwdParams p) {
     bool dead = false;
     int cons_end = 0;
     int gen = 0;
+    bool l2_prev = false, l2_next = false;
+#if VT_CHAIN
+    if (L > 1) {
+        // Which neighbours share this workgroup's XCD (and therefore its L2)?  Every slot publishes 1 + XCC_ID once; chain
+        // neighbours on the same XCD exchange their tiles through the L2 (plain stores, agent-scope loads), any other
+        // pair through memory.  Round-robin dispatch puts consecutive slots on one XCD, but nothing here relies on it.
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 15) + 1;
+        __amdgpu_buffer_rsrc_t rx = make_rsrc(p.chain_xcc, (unsigned)gridDim.x * 4u);
+        if (threadIdx.x == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)xcc, rx, slot * 4, 0, CH_AUX);
+        const int j = slot % spx;
+        auto peer = [&](int s2) -> int {
+            int v = 0, it = 0;
+            while (v == 0 && it++ < (1 << 16)) {
+                v = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(rx, s2 * 4, 0, CH_AUX));
+                if (v == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            return v;      // 0 after ~0.1 s: the neighbour never started -> treated as "another XCD"
+        };
+        if ((j % L) != 0) {
+            l2_prev = peer(slot - 1) == xcc;
+            if (threadIdx.x == 0) atomicAdd(p.chain_ctr + (l2_prev ? 11 : 12), 1);     // diagnostics: links through L2 / memory
+        }
+        if ((j % L) != L - 1 && j != spx - 1 && slot + 1 < (int)gridDim.x) l2_next = peer(slot + 1) == xcc;
+    }
+#endif
     for (int item = slot; item < nitems; item += gridDim.x, ++gen) {
         const int kblk = item % nkb;
         bool has_prod = false, has_cons = false;
@@ -757,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void BWD_KERNEL(AttnBwdParams p) {
         const bool ragged = (kblk + 1) * 256 > p.S;
         const int role = (has_prod ? 1 : 0) | (has_cons ? 2 : 0);
         const int base = gen * nsteps;
-#define VT_BWD_CALL(R, ROLE_) BWD_BODY<R, PRESCALED, ROLE_>(p, smem, stage, item, slot, cons_end, base, dead)
+#define VT_BWD_CALL(R, ROLE_) BWD_BODY<R, PRESCALED, ROLE_>(p, smem, stage, item, slot, cons_end, base, l2_prev, l2_next, dead)
 #if VT_CHAIN
         switch (role) {
             case 0: if (ragged) VT_BWD_CALL(true, 0); else VT_BWD_CALL(false, 0); break;
@@ -807,8 +838,9 @@ __global__ __launch_bounds__(256) void DELTA_KERNEL(const bf16_t* o, const bf16_
     }
 }
 
-// workspace layout: [0,64) tickets + error word | [256, 256 + 32 nwg) counters | tiles from the next 4 KiB boundary
-static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 32 + 4095) & ~4095LL; }
+// workspace layout: [0,64) error word, diagnostics | [256, +32 slots) counters | [.., +4 slots) XCC ids | tiles from the next 4 KiB boundary
+static long long bwd_chain_xcc_off(long long slots) { return 256 + slots * 32; }
+static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 36 + 4095) & ~4095LL; }
 static long long bwd_chain_ws_bytes(long long slots) { return bwd_chain_tiles_off(slots) + slots * (long long)(CH_R * 16384); }
 static int g_bwd_slots = 0;      // persistent grid: one workgroup per CU, a multiple of 8
 // chain length: VT_BWD_CHAIN (1 = off), default 2 (measured best: see the header comment).  The persistent grid is one workgroup per CU (the kernel's 145 KiB
@@ -874,7 +906,7 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
     const long long nwg = (long long)nkb * H * B;
     if (nwg > 0x3fffffLL) return VT_ERR_BAD_SHAPE;
     // dQ hand-off chains: need the caller's workspace and enough co-resident workgroups per XCD (see the header comment)
-    p.chain_len = 1; p.chain_ctr = nullptr; p.chain_flags = nullptr; p.chain_tiles = nullptr;
+    p.chain_len = 1; p.chain_ctr = nullptr; p.chain_flags = nullptr; p.chain_xcc = nullptr; p.chain_tiles = nullptr;
     int L = bwd_chain_len();
     const long long pgrid = nwg < g_bwd_slots ? (nwg + 7) / 8 * 8 : g_bwd_slots;      // persistent grid, a multiple of 8
     const long long grid = pgrid;
@@ -888,6 +920,7 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
             p.chain_len = L;
             p.chain_ctr = (int*)ws;
             p.chain_flags = (int*)(ws + 256);
+            p.chain_xcc = (int*)(ws + bwd_chain_xcc_off(g_bwd_slots));
             p.chain_tiles = (float*)(ws + bwd_chain_tiles_off(g_bwd_slots));
         }
     }

@@ -12,7 +12,7 @@
 // ragged M / N edges read zeros.  The MFMA is issued as (W-frag, A-frag) so each lane ends up with 4
 // consecutive output columns of one row; the accumulators go through LDS once so the epilogue reads
 // residual / writes C in row-contiguous, fully coalesced 128-B segments.
-#include "common.h"
+#include "gemm_epilogue.h"
 
 // variant hooks (tools/build_variants.sh); the shipped build defines none of these
 #ifndef VT_SUFFIX
@@ -25,24 +25,6 @@
 #define VT_CAT(a, b) VT_CAT_(a, b)
 #define GEMM_KERNEL VT_CAT(gemm_tn_kernel, VT_SUFFIX)
 #define GEMM_ENTRY VT_CAT(vt_gemm_bf16, VT_SUFFIX)
-
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* W;
-    void* C;
-    const bf16_t* bias;       // [N] or null
-    const bf16_t* R;          // residual [*, ldr] (EPI_GATED_RES)
-    const float* gate_txt;    // fp32 gate for rows with (m % S) <  St, indexed [b*gate_bstride + n]
-    const float* gate_vid;    // fp32 gate for rows with (m % S) >= St
-    bf16_t* C2;               // second output: pre-activation (EPI_BIAS_GELU)
-    const bf16_t* U;          // saved pre-activation (EPI_DGELU)
-    int M, N, K;
-    int lda, ldw, ldc, ldr, ldc2, ldu;
-    int S, St, gate_bstride;  // rows per sample, text rows per sample, gate batch stride (elements)
-    int r_mod;                // if > 0 the residual row is (m % r_mod)  (positional table add)
-};
-
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_DGELU = 3 };
 
 #define BM 128
 #define BN 128
@@ -200,53 +182,7 @@ __global__ __launch_bounds__(256, 2) void GEMM_KERNEL(GemmParams p) {
             const int m = row0 + half * 64 + ml;
             if (m < p.M && n < p.N) {
                 f32x4 v = *(const f32x4*)(Cs + ml * CS_LD + ec);
-                float o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = v[j] + bias4[j];
-                if (EPI == EPI_BIAS_GELU) {
-                    u32x2 u2;
-                    u2[0] = pack2(o[0], o[1]);
-                    u2[1] = pack2(o[2], o[3]);
-                    *(u32x2*)(p.C2 + (size_t)m * p.ldc2 + n) = u2;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = gelu_tanh_f(o[j]);
-                } else if (EPI == EPI_GATED_RES) {
-                    if (p.C2 != nullptr) {           // branch output before gating (full fine-tune: d gate = sum dh * branch)
-                        u32x2 u2;
-                        u2[0] = pack2(o[0], o[1]);
-                        u2[1] = pack2(o[2], o[3]);
-                        *(u32x2*)(p.C2 + (size_t)m * p.ldc2 + n) = u2;
-                    }
-                    const int rr = p.r_mod > 0 ? (m % p.r_mod) : m;
-                    u32x2 r2 = *(const u32x2*)(p.R + (size_t)rr * p.ldr + n);
-                    float r[4] = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
-                                  __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
-                    if (p.gate_vid != nullptr) {
-                        const int b = m / p.S;
-                        const int s = m - b * p.S;
-                        const float* g = (s < p.St ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride + n;
-                        f32x4 g4 = *(const f32x4*)g;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = r[j] + g4[j] * o[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = r[j] + o[j];
-                    }
-                } else if (EPI == EPI_DGELU) {
-                    u32x2 u2 = *(const u32x2*)(p.U + (size_t)m * p.ldu + n);
-                    float u[4] = {__uint_as_float(u2[0] << 16), __uint_as_float(u2[0] & 0xffff0000u),
-                                  __uint_as_float(u2[1] << 16), __uint_as_float(u2[1] & 0xffff0000u)};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = o[j] * gelu_tanh_grad_f(u[j]);
-                }
-                if (OUT_F32) {
-                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
-                } else {
-                    u32x2 c2;
-                    c2[0] = pack2(o[0], o[1]);
-                    c2[1] = pack2(o[2], o[3]);
-                    *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = c2;
-                }
+                gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
             }
         }
         __syncthreads();
@@ -261,6 +197,24 @@ static int VT_CAT(launch, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
 }
 
 static bool VT_CAT(al16, VT_SUFFIX)(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// 256x256-tile kernel (gemm_big_bf16.hip) for the token-sized problems; 0 = choose by shape, 1 = always 128x128, 2 = always 256x256
+int VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(const GemmParams& p, int epilogue, int out_fp32, hipStream_t st);
+static int VT_CAT(g_gemm_tile, VT_SUFFIX) = 0;
+extern "C" int VT_CAT(vt_gemm_set_tile, VT_SUFFIX)(int mode) {
+    if (mode < 0 || mode > 2) return VT_ERR_BAD_SHAPE;
+    VT_CAT(g_gemm_tile, VT_SUFFIX) = mode;
+    return VT_OK;
+}
+static bool VT_CAT(use_big, VT_SUFFIX)(int M, int N, int K) {
+    const int mode = VT_CAT(g_gemm_tile, VT_SUFFIX);
+    if (mode) return mode == 2;
+    // r01 measurements (tools/kbench.py gemm, M = 35552): N=5760 K=1984 851 -> 1018 TF/s, N=7680 K=1920 986 -> 1083,
+    // N=1920 K=7680 933 -> 1003, but N=1920 K=1984 968 -> 911 (7.5 column tiles round up to 8 and the big tile's exposed
+    // prologue / epilogue is not amortised by a short K loop); at M = 17776 the two are within +-7 %.
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    return tiles >= 1024 && (N >= 4096 || K >= 4096);
+}
 
 extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                             int M, int N, int K, const void* bias, int epilogue, int out_fp32,
@@ -277,20 +231,25 @@ extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldc2 = ldc2; p.ldu = ldu;
     p.S = S > 0 ? S : 1; p.St = St; p.gate_bstride = gate_bstride; p.r_mod = r_mod;
     hipStream_t st = (hipStream_t)stream;
+    const bool big = VT_CAT(use_big, VT_SUFFIX)(M, N, K);
     switch (epilogue) {
         case EPI_BIAS:
+            if (big) return VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(p, epilogue, out_fp32, st);
             return out_fp32 ? VT_CAT(launch, VT_SUFFIX)<EPI_BIAS, true>(p, st) : VT_CAT(launch, VT_SUFFIX)<EPI_BIAS, false>(p, st);
         case EPI_BIAS_GELU:
             if (out_fp32 || C2 == nullptr || (ldc2 % 4) || !VT_CAT(al16, VT_SUFFIX)(C2)) return VT_ERR_BAD_SHAPE;
+            if (big) return VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(p, epilogue, 0, st);
             return VT_CAT(launch, VT_SUFFIX)<EPI_BIAS_GELU, false>(p, st);
         case EPI_GATED_RES:
             if (out_fp32 || R == nullptr || (ldr % 4) || !VT_CAT(al16, VT_SUFFIX)(R)) return VT_ERR_BAD_SHAPE;
             if (C2 != nullptr && ((ldc2 % 4) || !VT_CAT(al16, VT_SUFFIX)(C2))) return VT_ERR_BAD_SHAPE;
             if (gate_vid != nullptr && (gate_txt == nullptr || (gate_bstride % 4) || !VT_CAT(al16, VT_SUFFIX)(gate_vid) || !VT_CAT(al16, VT_SUFFIX)(gate_txt)))
                 return VT_ERR_BAD_SHAPE;
+            if (big) return VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(p, epilogue, 0, st);
             return VT_CAT(launch, VT_SUFFIX)<EPI_GATED_RES, false>(p, st);
         case EPI_DGELU:
             if (out_fp32 || U == nullptr || (ldu % 4) || !VT_CAT(al16, VT_SUFFIX)(U)) return VT_ERR_BAD_SHAPE;
+            if (big) return VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(p, epilogue, 0, st);
             return VT_CAT(launch, VT_SUFFIX)<EPI_DGELU, false>(p, st);
         default:
             return VT_ERR_UNSUPPORTED;

@@ -198,6 +198,11 @@ def attn_bwd_chain_errors() -> int:
     return sum(attn_bwd_chain_error(ws) for ws in _CHAIN_WS.values())
 
 
+def gemm_set_tile(mode: int = 0):
+    """tile selection of vt_gemm_bf16: 0 = by shape, 1 = always 128x128, 2 = always 256x256 (tuning / test knob)"""
+    check(load_library().vt_gemm_set_tile(mode), "vt_gemm_set_tile")
+
+
 def attn_bwd_set_chain(chain_len: int = 0, slots: int = 0):
     """tuning / test knob of the dQ hand-off chains (0 = defaults); see include/vt355.h"""
     check(load_library().vt_attn_bwd_set_chain(chain_len, slots), "vt_attn_bwd_set_chain")

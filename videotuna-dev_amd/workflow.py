@@ -107,6 +107,11 @@ class CogVideoXWorkFlow(nn.Module):
             emb = self.cond_stage([c for c in batch["caption"]])
         return {"videos": vids, "prompt_embeds": emb}
 
+    def encode_raw_batch(self, batch):
+        """reference-schema batch -> {"latents", "prompt_embeds"}: the callable to give vt355.prefetch.EncoderPrefetcher"""
+        b = self.get_batch_input(batch)
+        return {"latents": b["videos"], "prompt_embeds": b["prompt_embeds"]}
+
     def training_step(self, batch, batch_idx=0):
         b = self.get_batch_input(batch)
         # [B,C,F,H,W] -> [B,F,C,H,W] (cogvideo_pl.py:817-819); the diffusion math runs in fp32, the DiT in bf16

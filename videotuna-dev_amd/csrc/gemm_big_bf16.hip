@@ -9,7 +9,7 @@
 // 256x256x64 with 8 waves (2 x 4), each wave owning 128x64 = 4x2 tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator
 // registers, two waves per SIMD): 24 KiB of LDS reads per wave per K-tile for 1 Mi flop -> the LDS pipe is ~75 % busy
 // at full MFMA rate.  Operands are staged by LDS-DMA (buffer_load ... lds, XOR swizzle applied to the source chunk),
-// double-buffered (2 x 64 KiB); the accumulators leave through LDS in four 64-row slabs so that the epilogue reads
+// double-buffered (2 x 64 KiB); the accumulators leave through LDS in eight 32-row slabs so that the epilogue reads
 // residuals / writes C in row-contiguous 512-B segments.
 #include "gemm_epilogue.h"
 
@@ -25,8 +25,48 @@
 #define GB_BN 256
 #define GB_BK 64
 #define GB_STAGE 65536      // A 32 KiB | W 32 KiB
-#define GB_CS_LD 260        // fp32 row stride of the epilogue staging slab (64 rows x 260 floats = 65 KiB)
+#define GB_CS_LD 260        // fp32 row stride of the epilogue staging slab (32 rows x 260 floats = 32.5 KiB)
 
+typedef int gb_i32x4 __attribute__((ext_vector_type(4)));
+
+// workgroup barrier that only orders LDS traffic (s_waitcnt lgkmcnt(0)); __syncthreads() would also drain vmcnt
+__device__ __forceinline__ void gb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct GbTile {
+    int row0, col0;
+    const bf16_t* a;        // first row of the tile in A / W; the descriptors are bounded by the rest of the matrix
+    const bf16_t* w;
+    unsigned a_bytes, w_bytes;
+};
+__device__ __forceinline__ gb_i32x4 gb_words(const void* base, unsigned bytes) {     // raw descriptor words (inline-asm operand)
+    const unsigned long long a = (unsigned long long)base;
+    return (gb_i32x4){(int)(unsigned)a, (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+
+__device__ __forceinline__ GbTile gb_tile(const GemmParams& p, int id, int nbm, int nbn) {
+    // grouped ordering (4 row-tiles per group, column-tiles outer): the 32 workgroups of an XCD that run together share
+    // A row-panels / W column-panels in its L2
+    const int GM = 4;
+    const int in_group = GM * nbn;
+    const int group = id / in_group;
+    const int first_m = group * GM;
+    const int gsz = min(nbm - first_m, GM);
+    GbTile t;
+    t.row0 = (first_m + (id % in_group) % gsz) * GB_BM;
+    t.col0 = ((id % in_group) / gsz) * GB_BN;
+    const long long a_rem = (long long)(p.M - t.row0) * p.lda * 2;
+    const long long w_rem = (long long)(p.N - t.col0) * p.ldw * 2;
+    t.a = p.A + (size_t)t.row0 * p.lda;
+    t.w = p.W + (size_t)t.col0 * p.ldw;
+    t.a_bytes = (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem);
+    t.w_bytes = (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem);
+    return t;
+}
+
+// PERSISTENT: one workgroup per CU (128 KiB of LDS), slot = (XCD, index inside the XCD) under round-robin dispatch;
+// generation g of slot s computes tile g * G + s.  The first K-tile of the NEXT output tile is fetched while the last
+// K-tile of the current one is multiplied and its epilogue runs, so neither a workgroup launch nor the first HBM round
+// trip of a tile is exposed.
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * GB_STAGE];
@@ -34,22 +74,10 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;                  // 2 x 4 waves: rows 128 wm .., columns 64 wn ..
     const int nbm = (p.M + GB_BM - 1) / GB_BM, nbn = (p.N + GB_BN - 1) / GB_BN;
-    // XCD-aware id, then grouped ordering (4 row-tiles per group, column-tiles outer): the 32 workgroups of an XCD
-    // that run together share A row-panels / W column-panels in its L2
-    const int id = xcd_remap(blockIdx.x, nbm * nbn);
-    const int GM = 4;
-    const int in_group = GM * nbn;
-    const int group = id / in_group;
-    const int first_m = group * GM;
-    const int gsz = min(nbm - first_m, GM);
-    const int tile_m = first_m + (id % in_group) % gsz;
-    const int tile_n = (id % in_group) / gsz;
-    const int row0 = tile_m * GB_BM, col0 = tile_n * GB_BN;
-
-    const long long a_rem = (long long)(p.M - row0) * p.lda * 2;
-    const long long w_rem = (long long)(p.N - col0) * p.ldw * 2;
-    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (size_t)row0 * p.lda, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
-    __amdgpu_buffer_rsrc_t rw = make_rsrc(p.W + (size_t)col0 * p.ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
+    const int ntiles = nbm * nbn;
+    const int spx = gridDim.x >> 3;
+    const int slot = (int)(blockIdx.x & 7) * spx + (int)(blockIdx.x >> 3);
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- LDS-DMA staging: a K-tile of A (and of W) is 32 blocks of 1 KiB = 8 rows x 128 B; wave w moves blocks
     // w, w+8, w+16, w+24 of each operand.  Lane l lands at (row l>>3, physical chunk l&7) of its block and fetches
@@ -62,8 +90,9 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
         a_voff[j] = row * p.lda * 2 + ((dcp ^ drl) << 4);
         w_voff[j] = row * p.ldw * 2 + ((dcp ^ drl) << 4);
     }
-    auto dma = [&](int kt, int buf) {
+    auto dma = [&](const GbTile& t, int kt, int buf) {
         const int soff = kt * GB_BK * 2;
+        __amdgpu_buffer_rsrc_t ra = make_rsrc(t.a, t.a_bytes), rw = make_rsrc(t.w, t.w_bytes);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             char* dst = smem + buf * GB_STAGE + (wave + 8 * j) * 1024;
@@ -71,90 +100,121 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 32768), 16, w_voff[j], soff, 0, 0);
         }
     };
-
-    // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
-    // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
-    f32x16 acc[2][4];
+    // the same transfer through inline asm, for the cross-tile prefetch: the compiler orders every later LDS access behind
+    // an LDS-DMA it knows about, which would park the whole epilogue behind the fetch.  Safe: it is older than every memory
+    // operation of the epilogue (vmcnt retires in order, so each wait the compiler computes there also covers it), and the
+    // next tile starts with a full barrier (vmcnt(0)).
+    auto dma_hidden = [&](const GbTile& t, int buf) {
+        const gb_i32x4 ra = gb_words(t.a, t.a_bytes), rw = gb_words(t.w, t.w_bytes);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const unsigned dst = smem_lds + buf * GB_STAGE + (wave + 8 * j) * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(a_voff[j]), "s"(ra) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst + 32768), "v"(w_voff[j]), "s"(rw) : "memory");
+        }
+    };
 
     const int nk = p.K / GB_BK;
-    dma(0, 0);
-    __syncthreads();
     const int fr = lane & 31;             // row inside a 32-row fragment
     const int fh = lane >> 5;             // which 8-element half of a 16-deep k-step
     const int fx = lane & 7;              // == (row & 7) of every fragment row this lane reads
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
-        const char* As = smem + buf * GB_STAGE + (wm * 128 + fr) * 128;
-        const char* Ws = smem + buf * GB_STAGE + 32768 + (wn * 64 + fr) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = (((ks * 2 + fh) ^ fx) << 4);
-            bf16x8 af[4], wf[2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(As + t * 4096 + coff);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) wf[t] = *(const bf16x8*)(Ws + t * 4096 + coff);
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
-        }
-        __syncthreads();       // its vmcnt(0) also retires the next tile's LDS-DMA
-    }
+    const int er = tid >> 6;              // epilogue: 0..7, row inside an 8-row pass
+    const int ec = (tid & 63) * 4;        // epilogue: first of this thread's 4 columns
 
-    // ---------------- epilogue: four 64-row slabs through LDS ----------------
-    float* Cs = (float*)smem;
-    const int er = tid >> 6;              // 0..7 : row inside an 8-row pass
-    const int ec = (tid & 63) * 4;        // first of this thread's 4 columns
-    const int n = col0 + ec;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && n < p.N) {
+    if (slot >= ntiles) return;
+    GbTile cur = gb_tile(p, slot, nbm, nbn);
+    int buf = 0;
+    dma(cur, 0, 0);
+    for (int tile = slot; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        GbTile nxt = cur;
+        if (has_next) nxt = gb_tile(p, tile + gridDim.x, nbm, nbn);
+
+        // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
+        // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
+        f32x16 acc[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
-    }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int slab = 0; slab < 4; ++slab) {
-        if (wm == (slab >> 1)) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int tm = 2 * (slab & 1) + t2;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        __syncthreads();                  // vmcnt(0): the first K-tile (fetched during the previous tile) has landed
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            if (!last) dma(cur, kt + 1, buf ^ 1);
+            else if (has_next) dma_hidden(nxt, buf ^ 1);
+            const char* As = smem + buf * GB_STAGE + (wm * 128 + fr) * 128;
+            const char* Ws = smem + buf * GB_STAGE + 32768 + (wn * 64 + fr) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int coff = (((ks * 2 + fh) ^ fx) << 4);
+                bf16x8 af[4], wf[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(As + t * 4096 + coff);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[t] = *(const bf16x8*)(Ws + t * 4096 + coff);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+            }
+            if (!last) __syncthreads();   // its vmcnt(0) also retires the next K-tile's LDS-DMA
+            else gb_lds_barrier();        // the cross-tile prefetch keeps flying
+            buf ^= 1;
+        }
+
+        // ---------------- epilogue: eight 32-row slabs through the stage that was just consumed ----------------
+        float* Cs = (float*)(smem + (buf ^ 1) * GB_STAGE);
+        const int n = cur.col0 + ec;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n < p.N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+        }
+#pragma unroll
+        for (int slab = 0; slab < 8; ++slab) {
+            if (wm == (slab >> 2)) {
+                const int tm = slab & 3;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int ml = t2 * 32 + fr;
                         const int nl = wn * 64 + tn * 32 + 8 * q + 4 * fh;
-                        *(f32x4*)(Cs + ml * GB_CS_LD + nl) =
+                        *(f32x4*)(Cs + fr * GB_CS_LD + nl) =
                             (f32x4){acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
                     }
             }
-        }
-        __syncthreads();
+            gb_lds_barrier();
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int ml = pass * 8 + er;
-            const int m = row0 + slab * 64 + ml;
-            if (m < p.M && n < p.N) {
-                const f32x4 v = *(const f32x4*)(Cs + ml * GB_CS_LD + ec);
-                gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
+            for (int pass = 0; pass < 4; ++pass) {
+                const int ml = pass * 8 + er;
+                const int m = cur.row0 + slab * 32 + ml;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = *(const f32x4*)(Cs + ml * GB_CS_LD + ec);
+                    gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
+                }
             }
+            gb_lds_barrier();
         }
-        __syncthreads();
+        cur = nxt;
     }
 }
 
 template <int EPI, bool F32>
 static int VT_CAT(launch_big, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + GB_BM - 1) / GB_BM, nbn = (p.N + GB_BN - 1) / GB_BN;
-    hipLaunchKernelGGL((GEMM_BIG_KERNEL<EPI, F32>), dim3(nbm * nbn), dim3(512), 0, st, p);
+    static int slots = 0;                 // persistent grid: one workgroup per CU, a multiple of 8
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        slots = cus >= 8 ? cus / 8 * 8 : 8;
+    }
+    const int ntiles = nbm * nbn;
+    const int grid = ntiles < slots ? (ntiles + 7) / 8 * 8 : slots;
+    hipLaunchKernelGGL((GEMM_BIG_KERNEL<EPI, F32>), dim3(grid), dim3(512), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -27,6 +27,16 @@ def main():
     which = sys.argv[1:] or ["gemm", "attn", "mem"]
     S, H, d = 17776, 30, 1920
     res = {}
+    if "gemmq" in which:      # one shape, both tilings, few launches: the PMC target (tools/pmc_kbench.sh)
+        M, N, K = 2 * S, 5760, 1984
+        a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=dev); b = torch.zeros(N, dtype=BF, device=dev)
+        for mode in (1, 2):
+            ops.gemm_set_tile(mode)
+            for _ in range(4):
+                ops.gemm(a, w, out, b)
+        torch.cuda.synchronize()
+        ops.gemm_set_tile(0)
     if "gemm" in which:
         for (M, N, K, name) in [(2 * S, 5760, 1984, "qkv2"), (2 * S, 1920, 1984, "out2"), (2 * S, 7680, 1920, "ff1_2"), (2 * S, 1920, 7680, "ff2_2"), (2 * S, 1984, 5760, "dqkv2"), (2 * S, 1984, 1920, "dout2"),
                                 (S, 5760, 1984, "qkv"), (S, 1920, 1984, "out"), (S, 7680, 1920, "ff1"), (S, 1920, 7680, "ff2"),

@@ -209,11 +209,12 @@ extern "C" int VT_CAT(vt_gemm_set_tile, VT_SUFFIX)(int mode) {
 static bool VT_CAT(use_big, VT_SUFFIX)(int M, int N, int K) {
     const int mode = VT_CAT(g_gemm_tile, VT_SUFFIX);
     if (mode) return mode == 2;
-    // r01 measurements (tools/kbench.py gemm, M = 35552): N=5760 K=1984 851 -> 1018 TF/s, N=7680 K=1920 986 -> 1083,
-    // N=1920 K=7680 933 -> 1003, but N=1920 K=1984 968 -> 911 (7.5 column tiles round up to 8 and the big tile's exposed
-    // prologue / epilogue is not amortised by a short K loop); at M = 17776 the two are within +-7 %.
+    // r01 measurements (tools/kbench.py gemm), 128x128 -> 256x256 tile, TF/s:
+    //   M=35552: N=5760 K=1984 851 -> 1028 | N=7680 K=1920 986 -> 1121 | N=1920 K=7680 933 -> 1039 | N=1984 K=5760 941 -> 1044
+    //            N=1920 K=1984 968 ->  920 (7.5 column tiles round up to 8; short K loop)
+    //   M=17776: N=5760 1007 -> 1048 | N=7680 962 -> 1072 | N=1920 K=7680 918 -> 900 | N=1984 K=5760 975 -> 913
     const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
-    return tiles >= 1024 && (N >= 4096 || K >= 4096);
+    return (N >= 4096 && tiles >= 512) || (K >= 4096 && tiles >= 1024);
 }
 
 extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* C, int ldc,

@@ -81,14 +81,19 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
 
     // ---- LDS-DMA staging: a K-tile of A (and of W) is 32 blocks of 1 KiB = 8 rows x 128 B; wave w moves blocks
     // w, w+8, w+16, w+24 of each operand.  Lane l lands at (row l>>3, physical chunk l&7) of its block and fetches
-    // logical chunk (l&7) ^ (row&7); rows past M / N read zeros (bounds check).
+    // logical chunk (l&7) ^ swz(row); rows past M / N read zeros (bounds check).
+    // swz(row) = (row >> 1) & 7: a 32-row MFMA fragment is read by ds_read_b128 in the lane groups {0-3,12-15,20-27},
+    // {4-11,16-19,28-31} (+32); two rows of a group collide when they have the same parity (128-B rows, 256-B bank
+    // period) and the same physical chunk, and (row >> 1) & 7 is distinct over the 8 same-parity rows of every group.
+    // (row & 7, the 16-row-fragment swizzle of gemm_bf16.hip, gave 47 % conflict cycles here: rows 12 and 20 collide.)
     const int drl = lane >> 3, dcp = lane & 7;
     int a_voff[4], w_voff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = 8 * (wave + 8 * j) + drl;
-        a_voff[j] = row * p.lda * 2 + ((dcp ^ drl) << 4);
-        w_voff[j] = row * p.ldw * 2 + ((dcp ^ drl) << 4);
+        const int sw = (row >> 1) & 7;
+        a_voff[j] = row * p.lda * 2 + ((dcp ^ sw) << 4);
+        w_voff[j] = row * p.ldw * 2 + ((dcp ^ sw) << 4);
     }
     auto dma = [&](const GbTile& t, int kt, int buf) {
         const int soff = kt * GB_BK * 2;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     const int nk = p.K / GB_BK;
     const int fr = lane & 31;             // row inside a 32-row fragment
     const int fh = lane >> 5;             // which 8-element half of a 16-deep k-step
-    const int fx = lane & 7;              // == (row & 7) of every fragment row this lane reads
+    const int fx = (fr >> 1) & 7;         // swz(row) of every fragment row this lane reads (tile rows are 32-aligned)
     const int er = tid >> 6;              // epilogue: 0..7, row inside an 8-row pass
     const int ec = (tid & 63) * 4;        // epilogue: first of this thread's 4 columns
 

@@ -93,16 +93,24 @@ def test_gemm_full_block_shape(dev):
     assert ((cs - cr).abs() / (ref.abs().sum(0) + 1e-6)).max() < 2e-3
 
 
-def test_one_full_size_block_train_step(dev):
-    """CogVideoX-2B dimensions (d 1920, 30 heads, S 17 776, text 226 x 4096) with ONE transformer block: loss and every
+@pytest.mark.parametrize("family", ["2b", "5b"])
+def test_one_full_size_block_train_step(dev, family):
+    """CogVideoX-2B dimensions (d 1920, 30 heads) and CogVideoX-5B dimensions (d 3072, 48 heads, rotary q/k with the
+    49x480x720 tables of cogvideo_pl.py:442-473), S 17 776, text 226 x 4096, with ONE transformer block: loss and every
     LoRA gradient against the fp32 oracle on the same bf16-rounded weights."""
     from vt355.dit import CogVideoXTransformer3DModel
     from vt355.lora import LoraConfig, get_peft_model
+    from vt355.rope import prepare_rotary_positional_embeddings
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.selfcheck import oracle_params
     from vt355.workflow import _LossFn
-    cfg = O.DiTConfig(num_layers=1)
-    model = CogVideoXTransformer3DModel(num_layers=1).init_weights(3).to(dev)
+    kw = dict(num_layers=1) if family == "2b" else dict(num_layers=1, num_attention_heads=48, use_rotary_positional_embeddings=True)
+    cfg = O.DiTConfig(**kw)
+    rope = prepare_rotary_positional_embeddings(480, 720, 13) if family == "5b" else None
+    if rope is not None:        # the workflow's tables == the oracle's own restatement (pinned to the reference's SAT tables)
+        ref_tabs = O.rope_3d_tables(64, O.resize_crop_region_for_grid((30, 45), (30, 45)), (30, 45), 13)
+        assert torch.equal(rope[0], ref_tabs[0]) and torch.equal(rope[1], ref_tabs[1])
+    model = CogVideoXTransformer3DModel(**kw).init_weights(3).to(dev)
     model.requires_grad_(False)
     peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
     st = peft._lora_state
@@ -118,7 +126,8 @@ def test_one_full_size_block_train_step(dev):
     t = torch.tensor([437])
     sched = CogVideoXDPMScheduler()
     noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
-    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev),
+               image_rotary_emb=None if rope is None else (rope[0].to(dev), rope[1].to(dev)))[0]
     sa, sb, w = sched.coefficients(t.to(dev))
     loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
     st.grad.zero_(); loss.backward()
@@ -127,7 +136,7 @@ def test_one_full_size_block_train_step(dev):
         v.requires_grad_(True)
     abar = O.alphas_cumprod_cogvideox().float()
     nref = noisy.float().cpu()
-    out_ref = O.dit_forward(P, cfg, nref, text.float(), t, Lo, st.scaling)
+    out_ref = O.dit_forward(P, cfg, nref, text.float(), t, Lo, st.scaling, image_rotary_emb=rope)
     pred = O.get_velocity(out_ref, nref, t, abar)
     loss_ref = torch.mean(((1 / (1 - abar[t])).view(-1, 1, 1, 1, 1) * (pred - x0) ** 2).reshape(1, -1), dim=1).mean()
     loss_ref.backward()

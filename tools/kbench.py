@@ -27,6 +27,19 @@ def main():
     which = sys.argv[1:] or ["gemm", "attn", "mem"]
     S, H, d = 17776, 30, 1920
     res = {}
+    if "attnq" in which:      # attention forward + backward, few launches: the PMC target (tools/pmc_kbench.sh)
+        B = 2
+        qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)
+        q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        o = torch.empty(B, S, d, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+        do = torch.randn(B, S, d, device=dev).to(BF)
+        dq = torch.zeros(B, S, d, device=dev); dk = torch.empty(B, S, d, dtype=BF, device=dev); dv = torch.empty_like(dk)
+        delta = torch.empty(B * H * S, device=dev)
+        ws = ops.attn_bwd_chain_workspace(B, H, S, dev)
+        for _ in range(3):
+            ops.attn_fwd(q, k, v, o, lse, B, H, S, q_prescaled=True)
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, S, q_prescaled=True, chain_ws=ws)
+        torch.cuda.synchronize()
     if "gemmq" in which:      # one shape, both tilings, few launches: the PMC target (tools/pmc_kbench.sh)
         M, N, K = 2 * S, 5760, 1984
         a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)

@@ -6,11 +6,10 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../videotuna-dev_amd/csrc" && pwd)"
 OUT="$HERE/../libvt355_exp.so"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics"
 mkdir -p "$HERE/obj_exp"; rm -f "$HERE"/obj_exp/*.o
-# dQ hand-off chains: ring depth / consumer hysteresis / cache policy of the tile exchange
+# attention backward A/B variants (see csrc/exp/README.md for what was measured with them)
 hipcc $F -DVT_SUFFIX=_nolink -DVT_CHAIN=0 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink.o" &
-for v in "4 1 17 17" "6 2 17 17" "8 0 17 17" "8 2 17 17" "8 2 0 16" "4 1 0 16" "8 2 0 17"; do set -- $v
-  hipcc $F -DVT_SUFFIX=_r$1h$2s$3l$4 -DCH_R=$1 -DCH_HYST=$2 -DCH_ST_AUX=$3 -DCH_LD_AUX=$4 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_r$1h$2s$3l$4.o" &
-done
+hipcc $F -DVT_SUFFIX=_stat -DVT_STATMFMA=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_stat.o" &
+hipcc $F -DVT_SUFFIX=_abl2 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl2.o" &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj_exp/*.o
 echo "built $OUT"

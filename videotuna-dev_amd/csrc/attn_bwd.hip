@@ -59,6 +59,10 @@
 #ifndef VT_DQSHIFT
 #define VT_DQSHIFT 0   // 1 = the dQ MFMAs of step t-1 run inside step t VALU-bound slots (measured SLOWER: 11.5 vs 8.9 ms, the atomics then leave every wave in one burst right after the barrier)
 #endif
+#ifndef VT_STATMFMA
+#define VT_STATMFMA 0 // 1 = the row constants (-lse2/c, -delta, key mask) enter S'' / dP' through one extra MFMA per tile (three
+#endif                // bf16 terms = 24 bits) instead of 32 v_accvgpr_write per tile.  Parity-clean and 26 % fewer VALU instructions
+                      // per step (480 -> 356), but measured SLOWER: 16.0 vs 15.8 ms with pairs, 20.4 vs 17.35 atomics-only (B=2)
 #ifndef VT_CHAIN
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
@@ -97,7 +101,8 @@ struct AttnBwdParams {
 #define DSIMG 32768
 #define QTILE 98304
 #define LSEOFF 131072
-#define BWD_LDS 132096
+#define STATF 132096             // row constants as MFMA operands: 2 buffers x {-lse2/c, -delta} x 64 rows x 32 B
+#define BWD_LDS (132096 + 8192)
 #define CH_STAGE_BYTES 16384     // incoming dQ tile of the chain predecessor: 4 waves x 4 KiB, a separate LDS object so
                                  // that the compiler does not order every ds_read of a step behind the DMA that fills it
 #ifndef CH_R
@@ -178,6 +183,23 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         kmask[0] = (key0 + 64 * w + r) < p.S ? 0.f : -1.0e30f;
         kmask[1] = (key0 + 64 * w + 32 + r) < p.S ? 0.f : -1.0e30f;
     }
+
+#if VT_STATMFMA
+    // B operands of the constant MFMAs: key (lane & 31), k = 8h..8h+7: ones against the three terms, the key mask against
+    // the 1.0 (S only); lanes 32-63 (k = 8..15) carry zeros
+    bf16x8 bS[2], bP;
+    {
+        const unsigned one2 = h == 0 ? 0x3f803f80u : 0u, one1 = h == 0 ? 0x00003f80u : 0u;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const unsigned km = (RAGGED && h == 0) ? (pack2(0.f, kmask[kb]) & 0xffff0000u) : 0u;
+            const u32x4 v = {one2, one1 | km, 0u, 0u};
+            bS[kb] = __builtin_bit_cast(bf16x8, v);
+        }
+        const u32x4 vp = {one2, one1, 0u, 0u};
+        bP = __builtin_bit_cast(bf16x8, vp);
+    }
+#endif
 
     // ---- per-lane LDS offsets ----
     int rowrd[4];                         // row read of the Q / dO tile (A operand of S / dP), k-step s
@@ -276,6 +298,21 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             *(u32x4*)(base + 8192 + st_lds[j]) = gdo[j];
         }
         *(float*)(smem + stat_lds + buf * 512) = gstat;
+#if VT_STATMFMA
+        {   // A-operand row of the constant: k = 0..2 hold hi + mid + lo (exact to 24 bits), k = 3 holds 1.0 (it multiplies
+            // the key-mask column of the B operand); the second 16-byte chunk (k = 8..15, lanes 32-63) is zero
+            const float x0 = gstat;
+            const float h0 = bf2f(f2bf(x0));
+            const float x1 = x0 - h0;
+            const float h1 = bf2f(f2bf(x1));
+            const float x2 = x1 - h1;
+            const u32x4 c0 = {pack2(h0, h1), pack2(x2, 1.0f), 0u, 0u};
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            char* dst = smem + STATF + buf * 4096 + (stat_is_lse ? 0 : 2048) + stat_i * 32;
+            *(u32x4*)dst = c0;
+            *(u32x4*)(dst + 16) = z;
+        }
+#endif
     };
 
     f32x16 dk_acc[2][2], dv_acc[2][2];
@@ -365,6 +402,19 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         };
         // accumulator init = row constants straight from LDS:  S'' starts at -lse2/c (+ key mask), dP' at -delta;
         // accumulator register 4g'+e <-> q = 32qs + 8g' + 4h + e
+#if VT_STATMFMA
+        // S'' and dP' start from ONE extra MFMA each: (row constant as an A operand) x (ones / key mask as a B operand), C = 0
+        const char* statf = smem + STATF + buf * 4096 + r * 32 + h * 16;
+        auto qk_init = [&](int qs, int kb, f32x16& sacc, f32x16& pacc) {
+            const bf16x8 al = *(const bf16x8*)(statf + qs * 1024);
+            const bf16x8 ad = *(const bf16x8*)(statf + 2048 + qs * 1024);
+            f32x16 z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.f;
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bS[kb], z, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bP, z, 0, 0, 0);
+        };
+#else
         auto qk_init = [&](int qs, int kb, f32x16& sacc, f32x16& pacc) {
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
@@ -374,6 +424,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 for (int e = 0; e < 4; ++e) { sacc[4 * gg + e] = RAGGED ? a[e] + kmask[kb] : a[e]; pacc[4 * gg + e] = c[e]; }
             }
         };
+#endif
         // MFMA number m (0..7) of QK: k-step m>>1, S for even m, dP for odd m
         auto qk_mfma = [&](int m, int kb, const bf16x8 (&qa)[4], const bf16x8 (&doa)[4], f32x16& sacc, f32x16& pacc) {
             if ((m & 1) == 0) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[m >> 1], kf[kb][m >> 1], sacc, 0, 0, 0);

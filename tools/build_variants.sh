@@ -9,6 +9,9 @@ mkdir -p "$HERE/obj_exp"; rm -f "$HERE"/obj_exp/*.o
 # attention backward A/B variants (see csrc/exp/README.md for what was measured with them)
 hipcc $F -DVT_SUFFIX=_nolink -DVT_CHAIN=0 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink.o" &
 hipcc $F -DVT_SUFFIX=_stat -DVT_STATMFMA=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_stat.o" &
+for st in max-ilp max-memory-clause iterative-ilp iterative-minreg; do
+  hipcc $F -mllvm -amdgpu-sched-strategy=$st -DVT_SUFFIX=_$(echo $st | tr - _) -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_$st.o" &
+done
 hipcc $F -DVT_SUFFIX=_abl2 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl2.o" &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj_exp/*.o

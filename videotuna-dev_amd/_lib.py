@@ -14,7 +14,8 @@ class VtError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libvt355.so")
+    # VT355_LIB: an alternative build of the same ABI (compiler-flag experiments, tools/); default = the in-tree library
+    return os.environ.get("VT355_LIB") or os.path.join(_HERE, "libvt355.so")
 
 
 # name -> argtypes ; all return int unless listed in _RESTYPE

@@ -1,18 +1,24 @@
 #!/bin/bash
 # Build libvt355.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [outdir]
+# VT_OBJ_DIR / VT_LIB_NAME / VT_SCHED_<file>=<strategy> let tools/ build flag experiments next to the shipped library.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
-mkdir -p "$HERE/obj"
+OBJ="${VT_OBJ_DIR:-$HERE/obj}"
+LIB="${VT_LIB_NAME:-libvt355.so}"
+mkdir -p "$OBJ"
+# per-file LLVM scheduling strategy (measured, r01): attn_bwd 15.70 -> 15.33 ms with max-ilp
+sched_of() { local v="VT_SCHED_$1"; if [ -n "${!v:-}" ]; then echo "${!v}"; elif [ "$1" = attn_bwd ]; then echo max-ilp; fi; }
 pids=()
 for f in api gemm_bf16 gemm_big_bf16 gemm_nt_bf16 attn_fwd attn_bwd norm elementwise lora reduce; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_epilogue.h" -nt "$HERE/obj/$f.o" ]; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/gemm_epilogue.h" -nt "$OBJ/$f.o" ] || [ "$HERE/build.sh" -nt "$OBJ/$f.o" ]; then
+    st="$(sched_of $f)"; extra=""; [ -n "$st" ] && [ "$st" != default ] && extra="-mllvm -amdgpu-sched-strategy=$st"
+    $HIPCC $FLAGS $extra -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvt355.so" "$HERE"/obj/*.o
-echo "built $OUT/libvt355.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIB" "$OBJ"/*.o
+echo "built $OUT/$LIB"

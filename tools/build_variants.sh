@@ -9,9 +9,13 @@ mkdir -p "$HERE/obj_exp"; rm -f "$HERE"/obj_exp/*.o
 # attention backward A/B variants (see csrc/exp/README.md for what was measured with them)
 hipcc $F -DVT_SUFFIX=_nolink -DVT_CHAIN=0 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink.o" &
 hipcc $F -DVT_SUFFIX=_stat -DVT_STATMFMA=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_stat.o" &
-for st in max-ilp max-memory-clause iterative-ilp iterative-minreg; do
-  hipcc $F -mllvm -amdgpu-sched-strategy=$st -DVT_SUFFIX=_$(echo $st | tr - _) -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_$st.o" &
-done
+hipcc $F -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8.o" &
+hipcc $F -DVT_W8=0 -DVT_SUFFIX=_w4 -mllvm -amdgpu-sched-strategy=max-ilp -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_w4.o" &
+hipcc $F -DCH_R=8 -DCH_HYST=2 -DVT_SUFFIX=_r8h2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_r8h2.o" &
+hipcc $F -DBWD_LDS_PAD=8192 -DVT_SUFFIX=_pad8k -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_pad8k.o" &
+hipcc $F -DVT_SUFFIX=_same -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_same.o" &
+hipcc $F -DW8_NOATOMICS=1 -DVT_SUFFIX=_w8na -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8na.o" &
+hipcc $F -DVT_SUFFIX=_nolink_abl2 -DVT_CHAIN=0 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink_abl2.o" &
 hipcc $F -DVT_SUFFIX=_abl2 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl2.o" &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj_exp/*.o

@@ -4,18 +4,21 @@
 // videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871 (loss.backward() under PL).
 // P is recomputed from Q, K and the forward's log2-domain LSE; the S x S matrices never touch HBM.
 //
-// Structure: one workgroup = 4 waves (one per SIMD, up to 512 registers each) = 256 keys of one
-// (batch, head); wave w owns keys [64w, 64w+64) and keeps dK^T and dV^T for them in 128 accumulator
-// registers while the workgroup sweeps all queries in steps of 64 rows.
+// Structure (shipped, VT_W8=1): one workgroup = 8 waves (two per SIMD, <= 256 registers each, all in VGPRs) = 256 keys
+// of one (batch, head); wave w owns keys [32w, 32w+32) and keeps dK^T and dV^T for them in 64 accumulator registers
+// while the workgroup sweeps all queries in steps of 64 rows.  (VT_W8=0: 4 waves x 64 keys, one per SIMD, all 512
+// registers, software-pipelined in program order -- the first version; with one wave per SIMD MFMA and VALU were busy
+// at the same time only 13 % of the cycles, and half of its VALU instructions were AGPR<->VGPR moves.)
 //   * S = Q K^T and dP = dO V^T are computed with the KEY on the MFMA lane (K / V fragments live in
-//     registers for the whole kernel), so the fp32 tiles P and dS are, after bf16 packing, directly
+//     registers for the whole key block), so the fp32 tiles P and dS are, after bf16 packing, directly
 //     the B operands of dV^T += dO^T P and dK^T += Q^T dS (A operands = transposed LDS reads of the
 //     dO / Q tiles, ds_read_b64_tr_b16).
-//   * -delta (delta = rowsum(dO*O)) is loaded as the initial accumulator of dP.
-//   * only dS crosses LDS: every wave writes its [64 keys][64 q] part of a [256][64] image; after
-//     one barrier each wave computes one 32x32 tile of dQ (its (q-half, d-half)) over all 256 keys
-//     and adds it to a fp32 dQ buffer with global_atomic_add_f32 (one register of a 32x32
-//     accumulator = two full 128-B row segments, the full-rate atomic shape).
+//   * -lse2/c and -delta (delta = rowsum(dO*O)) are loaded as the initial accumulators of S'' and dP'.
+//   * only dS crosses LDS: every wave writes its [32 keys][64 q] part of a [256][64] image; after
+//     one barrier waves 0..3 each compute one 32x32 tile of dQ (its (q-half, d-half)) over all 256 keys
+//     and add it to a fp32 dQ buffer with buffer_atomic_add_f32 (one register of a 32x32 accumulator = two full
+//     128-B row segments) -- or hand it to the next key block (chains, below) -- while waves 4..7 already start
+//     the next step (the dS image is double-buffered).
 // All four LDS images (K block, dS, Q tile, dO tile) have 128-B rows and share one XOR swizzle that
 // is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
 //
@@ -63,6 +66,11 @@
 #define VT_STATMFMA 0 // 1 = the row constants (-lse2/c, -delta, key mask) enter S'' / dP' through one extra MFMA per tile (three
 #endif                // bf16 terms = 24 bits) instead of 32 v_accvgpr_write per tile.  Parity-clean and 26 % fewer VALU instructions
                       // per step (480 -> 356), but measured SLOWER: 16.0 vs 15.8 ms with pairs, 20.4 vs 17.35 atomics-only (B=2)
+#ifndef VT_W8
+#define VT_W8 1       // 1 = eight waves per workgroup (32 keys each, two per SIMD), 0 = four (64 keys each, one per SIMD, software-
+                      // pipelined): r01, B=2, pairs: 14.3 vs 15.9 ms; without any atomics 11.5 vs 13.3 ms
+#endif
+#define BWD_THREADS (VT_W8 ? 512 : 256)
 #ifndef VT_CHAIN
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
@@ -102,7 +110,10 @@ struct AttnBwdParams {
 #define QTILE 98304
 #define LSEOFF 131072
 #define STATF 132096             // row constants as MFMA operands: 2 buffers x {-lse2/c, -delta} x 64 rows x 32 B
-#define BWD_LDS (132096 + 8192)
+#ifndef BWD_LDS_PAD
+#define BWD_LDS_PAD 0
+#endif
+#define BWD_LDS (132096 + (VT_STATMFMA ? 8192 : BWD_LDS_PAD))
 #define CH_STAGE_BYTES 16384     // incoming dQ tile of the chain predecessor: 4 waves x 4 KiB, a separate LDS object so
                                  // that the compiler does not order every ds_read of a step behind the DMA that fills it
 #ifndef CH_R
@@ -130,6 +141,321 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v8);
 }
 
+#if VT_W8
+// EIGHT-wave body (VT_W8): wave w owns keys [32w, 32w+32) of the 256-key block -- half the accumulators and half the
+// softmax work per wave, two waves per SIMD so that one wave's exp2 / packing runs under the other's MFMAs (the four-wave
+// body has MFMA and VALU busy at the same time only 13 % of the cycles).  Waves 0..3 run the dQ phase (and the chain
+// hand-off) exactly as the four-wave body does while waves 4..7 already start the next step.
+template <bool RAGGED, bool PRESCALED, int ROLE>
+__device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, char* stage, const int id, const int slot,
+                                         const int cons_end, const int base, const bool l2_prev, const bool l2_next,
+                                         bool& dead) {
+    constexpr bool has_prod = (ROLE & 1) != 0, has_cons = (ROLE & 2) != 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+    const int r = lane & 31, h = lane >> 5, g = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
+    const int nkb = (p.S + 255) / 256;
+    const int kblk = id % nkb, bh = id / nkb;
+    const int head = bh % p.H, b = bh / p.H;
+    const int key0 = kblk * 256;
+
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 64;
+    const bf16_t* kb_ = p.k + (size_t)b * p.k_bs + head * 64;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 64;
+    const bf16_t* dob = p.dout + (size_t)b * p.do_bs + head * 64;
+    __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)((long long)(p.S - 1) * p.q_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb_, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rdo = make_rsrc(dob, (unsigned)((long long)(p.S - 1) * p.do_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rdq = make_rsrc(p.dq + (size_t)b * p.dq_bs + head * 64, (unsigned)((long long)(p.S - 1) * p.dq_rs * 4 + 256));
+    const float* lse_b = p.lse2 + (size_t)bh * p.S;
+    const float* dl_b = p.delta + (size_t)bh * p.S;
+
+    // ---- K block image (B operand of dQ): 256 keys x 8 chunks, 4 per thread ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 512 * j;
+        const int key = i >> 3, c = i & 7;
+        u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)((key0 + key) * p.k_rs * 2) + c * 16, 0, 0));
+        *(u32x4*)(smem + KIMG + swz_off(key, c)) = v;
+    }
+    // ---- K / V fragments of this wave's 32 keys, resident for the whole key block ----
+    bf16x8 kf[4], vf[4];
+    {
+        const int key = key0 + 32 * w + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(key * p.k_rs * 2) + (16 * s + 8 * h) * 2, 0, 0));
+            vf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(key * p.v_rs * 2) + (16 * s + 8 * h) * 2, 0, 0));
+        }
+    }
+    const float kmask = (RAGGED && (key0 + 32 * w + r) >= p.S) ? -1.0e30f : 0.f;
+
+    // ---- per-lane LDS offsets (identical to csrc/attn_bwd.hip) ----
+    int rowrd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rowrd[s] = r * 128 + (((2 * s + h) ^ swz_f(r)) << 4);
+    int trA[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec) {
+            const int fx = ((ql >> 1) << 2) | (sec << 1) | h;
+            trA[dt][sec] = (4 * h + ql + 8 * sec) * 128 + (((4 * dt + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
+        }
+    const int qs_w = w & 1, dt_w = (w >> 1) & 1;          // dQ phase (waves 0..3): (q-half, d-half) of the 64x64 tile
+    int trQA[2], trQB[2];
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+        const int fx = ((ql >> 1) << 2) | (h << 1) | sec;
+        const int row = (8 * h + ql + 4 * sec) * 128;
+        trQA[sec] = row + (((4 * qs_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
+        trQB[sec] = row + (((4 * dt_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
+    }
+    const int fr = swz_f(r);
+    const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
+    const int dq_rowb = (int)(p.dq_rs * 4);
+
+    // ---- dQ hand-off chain (see the header comment); only the dQ waves (w < 4) take part ----
+    const int wu = w & 3;
+    const bool dqw = w < 4;
+    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 32u);
+    __amdgpu_buffer_rsrc_t rt_mine = make_rsrc(p.chain_tiles + (size_t)slot * (CH_R * 4096), CH_R * 16384);
+    const int fl_ready_me = (slot * 8 + wu) * 4, fl_cons_me = (slot * 8 + 4 + wu) * 4;
+    const int fl_ready_prod = ((slot - 1) * 8 + wu) * 4, fl_cons_next = ((slot + 1) * 8 + 4 + wu) * 4;
+    const int tile_voff = (wu * 256 + lane) * 16;
+    const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+    i32x4w rt_prod_w;
+    {
+        const unsigned long long a = (unsigned long long)(p.chain_tiles + (size_t)(has_prod ? slot - 1 : slot) * (CH_R * 4096));
+        rt_prod_w = (i32x4w){(int)(unsigned)a, (int)((a >> 32) & 0xffffu), CH_R * 16384, 0x00020000};
+    }
+    auto fl_load = [&](int off) -> int { return (int)__builtin_amdgcn_raw_buffer_load_b32(rfl, off, 0, CH_AUX); };
+    int spins_r = 0, spins_c = 0;
+    auto fl_wait = [&](int off, int need, int have, int& spins) {
+        int it = 0;
+        while (have < need && !dead) {
+            ++spins;
+            __builtin_amdgcn_s_sleep(4);
+            have = __builtin_amdgcn_readfirstlane(fl_load(off));
+            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; }
+        }
+    };
+
+    // ---- staging of the Q / dO tiles (64 rows x 8 chunks each): one chunk of each per thread ----
+    const int st_voq = (int)((tid >> 3) * p.q_rs * 2) + (tid & 7) * 16;
+    const int st_vodo = (int)((tid >> 3) * p.do_rs * 2) + (tid & 7) * 16;
+    const int st_lds = swz_off(tid >> 3, tid & 7);
+    const int stat_i = tid & 63;
+    const bool stat_is_lse = (tid & 64) == 0;
+    const float* stat_src = stat_is_lse ? lse_b : dl_b;
+    const float stat_mul = stat_is_lse ? (PRESCALED ? -1.0f : -1.0f / p.scale_log2) : -1.0f;
+    const int stat_lds = LSEOFF + (tid & 127) * 4;
+    u32x4 gq, gdo;
+    float gstat = 0.f;
+    auto gload = [&](int t) {
+        const int q0 = t * 64;
+        const int sq = (int)((long long)q0 * p.q_rs * 2), sdo = (int)((long long)q0 * p.do_rs * 2);
+        gq = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, st_voq, sq, 0));
+        gdo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, st_vodo, sdo, 0));
+        int qi = q0 + stat_i;
+        const bool ok = qi < p.S;
+        qi = ok ? qi : p.S - 1;
+        const float v = stat_src[qi] * stat_mul;
+        gstat = ok ? v : 0.f;
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + QTILE + buf * 16384;
+        *(u32x4*)(base + st_lds) = gq;
+        *(u32x4*)(base + 8192 + st_lds) = gdo;
+        *(float*)(smem + stat_lds + buf * 512) = gstat;     // threads t, t+128, t+256, t+384 write the same value
+    };
+
+    f32x16 dk_acc[2], dv_acc[2];          // [dt]: dK^T / dV^T of this wave's 32 keys
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk_acc[c][i] = 0.f; dv_acc[c][i] = 0.f; }
+
+    const float sc = p.scale_log2;
+    const int nsteps = (p.S + 63) / 64;
+    int pf_ready = 0;
+    if (has_prod && dqw) pf_ready = fl_load(fl_ready_prod);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int s_ready = (has_prod && dqw) ? __builtin_amdgcn_readfirstlane(pf_ready) : 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        int pf_cons = 0;
+        if (has_prod && dqw) {
+            if (s_ready < base + t + 1)
+                fl_wait(fl_ready_prod, base + (t + 1 + CH_HYST < nsteps ? t + 1 + CH_HYST : nsteps), s_ready, spins_r);
+            // hidden LDS-DMA of the predecessor's tile t (see the four-wave body for why it goes through inline asm)
+            if (l2_prev) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
+                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds"
+                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+            }
+            pf_ready = fl_load(fl_ready_prod);
+        }
+        if (has_cons && dqw) pf_cons = fl_load(fl_cons_next);
+        gload(t + 1);                                  // past the end: bounds-checked loads return zeros
+        const char* qimg = smem + QTILE + buf * 16384;
+        const char* doimg = qimg + 8192;
+        const float* lsel = (const float*)(smem + LSEOFF + buf * 512);
+        char* dsimg = smem + DSIMG + buf * 32768;
+
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            // S'' and dP' accumulators start from the row constants (-lse2/c [+ key mask], -delta)
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const f32x4 a = *(const f32x4*)(lsel + 32 * qs + 8 * gg + 4 * h);
+                const f32x4 c = *(const f32x4*)(lsel + 64 + 32 * qs + 8 * gg + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sacc[4 * gg + e] = RAGGED ? a[e] + kmask : a[e]; pacc[4 * gg + e] = c[e]; }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 qa = *(const bf16x8*)(qimg + qs * 4096 + rowrd[s]);
+                const bf16x8 doa = *(const bf16x8*)(doimg + qs * 4096 + rowrd[s]);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, vf[s], pacc, 0, 0, 0);
+            }
+            // P = exp2(c * S''), dS = P * dP'; both packed to bf16 pairs (B operands + dS image)
+            unsigned pw[8], dw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? sacc[2 * i] : sacc[2 * i] * sc);
+                const float p1 = __builtin_amdgcn_exp2f(PRESCALED ? sacc[2 * i + 1] : sacc[2 * i + 1] * sc);
+                pw[i] = pack2(p0, p1);
+                dw[i] = pack2(p0 * pacc[2 * i], p1 * pacc[2 * i + 1]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 pb4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+                const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, pb4), dsb = __builtin_bit_cast(bf16x8, db4);
+                const int ro = (32 * qs + 16 * s2) * 128;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 doT = tr_pair(doimg + ro + trA[dt][0], doimg + ro + trA[dt][1]);
+                    const bf16x8 qT = tr_pair(qimg + ro + trA[dt][0], qimg + ro + trA[dt][1]);
+                    dv_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pb, dv_acc[dt], 0, 0, 0);
+                    dk_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, dsb, dk_acc[dt], 0, 0, 0);
+                }
+            }
+            // dS image: row = key (32w + r), 8 bytes = q 32qs + 8g' + 4h + (0..3)
+            char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
+                *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+            }
+        }
+        lstore(buf ^ 1);
+        __syncthreads();
+
+        // ---- dQ tile (32 q x 32 d) over all 256 keys: waves 0..3 only; waves 4..7 go on with the next step ----
+        if (dqw) {
+            if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);      // the barrier drained the memory pipeline
+            const int s_cons = has_cons ? __builtin_amdgcn_readfirstlane(pf_cons) : 0;
+            f32x16 dq_acc;
+            if (has_prod) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *(const f32x4*)(stage + wu * 4096 + j * 1024 + lane * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq_acc[4 * j + e] = v[e];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 16; ++s3) {
+                const bf16x8 fa = tr_pair(dsimg + s3 * 2048 + trQA[0], dsimg + s3 * 2048 + trQA[1]);
+                const bf16x8 fb = tr_pair(smem + KIMG + s3 * 2048 + trQB[0], smem + KIMG + s3 * 2048 + trQB[1]);
+                dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, dq_acc, 0, 0, 0);
+            }
+            if (has_cons) {
+                const int a = base + t;
+                int need = a - CH_R + 1;
+                if (t < CH_R && need > cons_end) need = cons_end;
+                if (need > 0) fl_wait(fl_cons_next, need, s_cons, spins_c);
+                if (t > 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): tile t-1 is a step old
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)a, rfl, fl_ready_me, 0, CH_AUX);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = {dq_acc[4 * j], dq_acc[4 * j + 1], dq_acc[4 * j + 2], dq_acc[4 * j + 3]};
+                    if (l2_next)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024, (a % CH_R) * 16384, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024, (a % CH_R) * 16384, CH_AUX);
+                }
+            } else {
+                const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
+#if VT_ABL == 2
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
+                (void)soff;
+#else
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff,
+                                                                    soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
+#endif
+            }
+            if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);
+        }
+    }
+    if (dqw) {
+        if ((has_prod || has_cons) && lane == 0 && (spins_r | spins_c)) {
+            if (spins_r) atomicAdd(p.chain_ctr + 9, spins_r);
+            if (spins_c) atomicAdd(p.chain_ctr + 10, spins_c);
+        }
+        if (has_cons) {     // the last tile
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + nsteps), rfl, fl_ready_me, 0, CH_AUX);
+        }
+    }
+
+    // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----
+    const float dk_mul = PRESCALED ? 0.6931471805599453f : p.scale;
+    {
+        const int key = key0 + 32 * w + r;
+        if (key < p.S) {
+            bf16_t* dkp = p.dk + (size_t)b * p.dk_bs + (size_t)key * p.dk_rs + head * 64;
+            bf16_t* dvp = p.dv + (size_t)b * p.dv_bs + (size_t)key * p.dv_rs + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    u32x2 a, c;
+                    a[0] = pack2(dk_acc[dt][4 * gg + 0] * dk_mul, dk_acc[dt][4 * gg + 1] * dk_mul);
+                    a[1] = pack2(dk_acc[dt][4 * gg + 2] * dk_mul, dk_acc[dt][4 * gg + 3] * dk_mul);
+                    c[0] = pack2(dv_acc[dt][4 * gg + 0], dv_acc[dt][4 * gg + 1]);
+                    c[1] = pack2(dv_acc[dt][4 * gg + 2], dv_acc[dt][4 * gg + 3]);
+                    *(u32x2*)(dkp + 32 * dt + 8 * gg + 4 * h) = a;
+                    *(u32x2*)(dvp + 32 * dt + 8 * gg + 4 * h) = c;
+                }
+        }
+    }
+}
+
+#else
 // ROLE: bit 0 = has a chain predecessor (takes its running dQ tiles), bit 1 = has a successor (hands its tiles on instead of
 // adding them atomically).  A template parameter, not a runtime flag: each role gets its own register allocation -- with
 // runtime flags the atomic-only path of the same binary ran 26 % slower than the kernel without any chain code.
@@ -783,8 +1109,10 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     }
 }
 
+#endif   // VT_W8
+
 template <bool PRESCALED>
-__global__ __launch_bounds__(256, 1) void BWD_KERNEL(AttnBwdParams p) {
+__global__ __launch_bounds__(BWD_THREADS, 1) void BWD_KERNEL(AttnBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[BWD_LDS];
     __shared__ __attribute__((aligned(16))) char stage[CH_STAGE_BYTES];
     const int nkb = (p.S + 255) / 256;
@@ -975,8 +1303,8 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
             p.chain_tiles = (float*)(ws + bwd_chain_tiles_off(g_bwd_slots));
         }
     }
-    if (q_prescaled) hipLaunchKernelGGL(BWD_KERNEL<true>, dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(BWD_KERNEL<false>, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (q_prescaled) hipLaunchKernelGGL(BWD_KERNEL<true>, dim3((unsigned)grid), dim3(BWD_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(BWD_KERNEL<false>, dim3((unsigned)grid), dim3(BWD_THREADS), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -9,8 +9,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unuse
 OBJ="${VT_OBJ_DIR:-$HERE/obj}"
 LIB="${VT_LIB_NAME:-libvt355.so}"
 mkdir -p "$OBJ"
-# per-file LLVM scheduling strategy (measured, r01): attn_bwd 15.70 -> 15.33 ms with max-ilp
-sched_of() { local v="VT_SCHED_$1"; if [ -n "${!v:-}" ]; then echo "${!v}"; elif [ "$1" = attn_bwd ]; then echo max-ilp; fi; }
+# per-file LLVM scheduling strategy (VT_SCHED_<file>=max-ilp ...).  Measured, r01: max-ilp helps the four-wave attention
+# backward (15.70 -> 15.33 ms) but not the shipped eight-wave one (14.3 -> 15.2) nor the GEMMs (-2..4 %): default everywhere.
+sched_of() { local v="VT_SCHED_$1"; if [ -n "${!v:-}" ]; then echo "${!v}"; fi; }
 pids=()
 for f in api gemm_bf16 gemm_big_bf16 gemm_nt_bf16 attn_fwd attn_bwd norm elementwise lora reduce; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/gemm_epilogue.h" -nt "$OBJ/$f.o" ] || [ "$HERE/build.sh" -nt "$OBJ/$f.o" ]; then

@@ -12,7 +12,7 @@ hipcc $F -DVT_SUFFIX=_stat -DVT_STATMFMA=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj
 hipcc $F -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8.o" &
 hipcc $F -DVT_W8=0 -DVT_SUFFIX=_w4 -mllvm -amdgpu-sched-strategy=max-ilp -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_w4.o" &
 hipcc $F -DCH_R=8 -DCH_HYST=2 -DVT_SUFFIX=_r8h2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_r8h2.o" &
-hipcc $F -DBWD_LDS_PAD=8192 -DVT_SUFFIX=_pad8k -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_pad8k.o" &
+hipcc $F -DVT_DQ16=1 -DVT_SUFFIX=_dq16 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_dq16.o" &
 hipcc $F -DVT_SUFFIX=_same -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_same.o" &
 hipcc $F -DW8_NOATOMICS=1 -DVT_SUFFIX=_w8na -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8na.o" &
 hipcc $F -DVT_SUFFIX=_nolink_abl2 -DVT_CHAIN=0 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink_abl2.o" &

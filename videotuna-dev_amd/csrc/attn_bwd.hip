@@ -71,6 +71,11 @@
                       // pipelined): r01, B=2, pairs: 14.3 vs 15.9 ms; without any atomics 11.5 vs 13.3 ms
 #endif
 #define BWD_THREADS (VT_W8 ? 512 : 256)
+#ifndef VT_DQ16
+#define VT_DQ16 0     // 1 = eight-wave body computes dQ as sixteen 16x16 tiles over ALL waves instead of four 32x32 tiles on waves
+                      // 0..3.  Parity-clean but measured SLOWER (B=2): pairs 16.3-17.6 vs 14.6 ms, atomics only 17.0 vs 16.8 -- eight
+                      // waves then issue hand-off stores / DMA / counters instead of four
+#endif
 #ifndef VT_CHAIN
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
@@ -100,7 +105,7 @@ struct AttnBwdParams {
     float scale, scale_log2;
     int chain_len;        // 1: one workgroup per key block, every one adds its dQ partial atomically; > 1: persistent + chains
     int* chain_ctr;       // [8] = error word                                    (zeroed by the host before the launch)
-    int* chain_flags;     // [slots][8]: ready[4 waves] | consumed[4 waves], in absolute steps (zeroed before the launch)
+    int* chain_flags;     // [slots][16]: ready[8 waves] | consumed[8 waves], in absolute steps (zeroed before the launch)
     int* chain_xcc;       // [slots] 1 + XCC_ID of the workgroup that runs the slot (0 = not started yet; zeroed before the launch)
     float* chain_tiles;   // [slots][CH_R][4 waves][4][64 lanes][4] fp32
 };
@@ -203,6 +208,24 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             const int fx = ((ql >> 1) << 2) | (sec << 1) | h;
             trA[dt][sec] = (4 * h + ql + 8 * sec) * 128 + (((4 * dt + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
         }
+#if VT_DQ16
+    // dQ phase: the 64x64 block as sixteen 16x16 tiles (v_mfma_f32_16x16x32_bf16), two per wave: q rows 16 qt .., d columns
+    // 32 dh + {0, 16}.  A = dS^T (rows q, k = key) and B = K^T (rows d, k = key) both come from transposed reads: group
+    // g = lane>>4 takes key rows 8g + 4 sec + ql of every 32-key k-step, 16 columns wide; with the images' swizzle the two
+    // blocks of a 32-lane half are 8 rows apart in the same columns -> conflict-free.
+    const int qt = w >> 1, dh = w & 1;
+    int trq16[2], trk16[2][2];
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+        const int row = 8 * g + 4 * sec + ql;
+        const int fxr = swz_f(row);
+        trq16[sec] = row * 128 + (((2 * qt + (pl >> 1)) ^ fxr) << 4) + (pl & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) trk16[j][sec] = row * 128 + (((2 * (2 * dh + j) + (pl >> 1)) ^ fxr) << 4) + (pl & 1) * 8;
+    }
+    const int dq_voff = (int)((16 * qt + 4 * g) * p.dq_rs * 4) + (32 * dh + (lane & 15)) * 4;
+    const int dq_rowb = (int)(p.dq_rs * 4);
+#else
     const int qs_w = w & 1, dt_w = (w >> 1) & 1;          // dQ phase (waves 0..3): (q-half, d-half) of the 64x64 tile
     int trQA[2], trQB[2];
 #pragma unroll
@@ -212,18 +235,26 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         trQA[sec] = row + (((4 * qs_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
         trQB[sec] = row + (((4 * dt_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
     }
-    const int fr = swz_f(r);
     const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
     const int dq_rowb = (int)(p.dq_rs * 4);
+#endif
+    const int fr = swz_f(r);
 
     // ---- dQ hand-off chain (see the header comment); only the dQ waves (w < 4) take part ----
-    const int wu = w & 3;
+#if VT_DQ16
+    const int wu = w;                 // every wave owns 2 KiB of a hand-off tile (2 x 16x16 fp32)
+    constexpr bool dqw = true;
+    constexpr int NT = 2, WTILE = 2048;
+#else
+    const int wu = w & 3;             // waves 0..3 own 4 KiB each (one 32x32 fp32 tile)
     const bool dqw = w < 4;
-    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 32u);
+    constexpr int NT = 4, WTILE = 4096;
+#endif
+    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 64u);
     __amdgpu_buffer_rsrc_t rt_mine = make_rsrc(p.chain_tiles + (size_t)slot * (CH_R * 4096), CH_R * 16384);
-    const int fl_ready_me = (slot * 8 + wu) * 4, fl_cons_me = (slot * 8 + 4 + wu) * 4;
-    const int fl_ready_prod = ((slot - 1) * 8 + wu) * 4, fl_cons_next = ((slot + 1) * 8 + 4 + wu) * 4;
-    const int tile_voff = (wu * 256 + lane) * 16;
+    const int fl_ready_me = (slot * 16 + wu) * 4, fl_cons_me = (slot * 16 + 8 + wu) * 4;
+    const int fl_ready_prod = ((slot - 1) * 16 + wu) * 4, fl_cons_next = ((slot + 1) * 16 + 8 + wu) * 4;
+    const int tile_voff = wu * WTILE + lane * 16;
     const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
     i32x4w rt_prod_w;
     {
@@ -294,15 +325,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             // hidden LDS-DMA of the predecessor's tile t (see the four-wave body for why it goes through inline asm)
             if (l2_prev) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
-                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                 :: "s"(stage_lds + wu * WTILE + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
                                     "s"(((base + t) % CH_R) * 16384) : "memory");
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds"
-                                 :: "s"(stage_lds + wu * 4096 + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
+                                 :: "s"(stage_lds + wu * WTILE + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
                                     "s"(((base + t) % CH_R) * 16384) : "memory");
             }
             pf_ready = fl_load(fl_ready_prod);
@@ -366,6 +397,63 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         lstore(buf ^ 1);
         __syncthreads();
 
+#if VT_DQ16
+        // ---- dQ: two 16x16 tiles per wave over all 256 keys (all eight waves) ----
+        {
+            if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);      // the barrier drained the memory pipeline
+            const int s_cons = has_cons ? __builtin_amdgcn_readfirstlane(pf_cons) : 0;
+            f32x4 dq16[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (has_prod) dq16[j] = *(const f32x4*)(stage + wu * WTILE + j * 1024 + lane * 16);
+                else dq16[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 8; ++s3) {
+                const bf16x8 fa = tr_pair(dsimg + s3 * 4096 + trq16[0], dsimg + s3 * 4096 + trq16[1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 fb = tr_pair(smem + KIMG + s3 * 4096 + trk16[j][0], smem + KIMG + s3 * 4096 + trk16[j][1]);
+                    dq16[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, dq16[j], 0, 0, 0);
+                }
+            }
+            if (has_cons) {
+                const int a = base + t;
+                int need = a - CH_R + 1;
+                if (t < CH_R && need > cons_end) need = cons_end;
+                if (need > 0) fl_wait(fl_cons_next, need, s_cons, spins_c);
+                if (t > 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): tile t-1 is a step old
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned)a, rfl, fl_ready_me, 0, CH_AUX);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (l2_next)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dq16[j]), rt_mine, tile_voff + j * 1024, (a % CH_R) * 16384, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dq16[j]), rt_mine, tile_voff + j * 1024, (a % CH_R) * 16384, CH_AUX);
+                }
+            } else {
+                const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
+#if VT_ABL == 2
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(dq16[j][e]));
+                (void)soff;
+#else
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // register e = q row 4g + e; 16 consecutive d per lane group
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq16[j][e] * p.scale, rdq, dq_voff,
+                                                                        soff + e * dq_rowb + 64 * j, 0);
+#endif
+            }
+            if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);
+        }
+    }
+#else
         // ---- dQ tile (32 q x 32 d) over all 256 keys: waves 0..3 only; waves 4..7 go on with the next step ----
         if (dqw) {
             if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);      // the barrier drained the memory pipeline
@@ -421,6 +509,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);
         }
     }
+#endif
     if (dqw) {
         if ((has_prod || has_cons) && lane == 0 && (spins_r | spins_c)) {
             if (spins_r) atomicAdd(p.chain_ctr + 9, spins_r);
@@ -556,10 +645,10 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 
     // ---- dQ hand-off chain (see the header comment): has_prod / has_cons are workgroup-uniform ----
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 32u);
+    __amdgpu_buffer_rsrc_t rfl = make_rsrc(p.chain_flags, (unsigned)gridDim.x * 64u);
     __amdgpu_buffer_rsrc_t rt_mine = make_rsrc(p.chain_tiles + (size_t)slot * (CH_R * 4096), CH_R * 16384);
-    const int fl_ready_me = (slot * 8 + wu) * 4, fl_cons_me = (slot * 8 + 4 + wu) * 4;
-    const int fl_ready_prod = ((slot - 1) * 8 + wu) * 4, fl_cons_next = ((slot + 1) * 8 + 4 + wu) * 4;
+    const int fl_ready_me = (slot * 16 + wu) * 4, fl_cons_me = (slot * 16 + 8 + wu) * 4;
+    const int fl_ready_prod = ((slot - 1) * 16 + wu) * 4, fl_cons_next = ((slot + 1) * 16 + 8 + wu) * 4;
     const int tile_voff = (wu * 256 + lane) * 16;          // + j * 1024, j = 0..3: registers 4j..4j+3 of the 32x32 dQ tile
     const unsigned stage_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
     i32x4w rt_prod_w;                                      // the predecessor's ring as raw descriptor words (inline asm operand)
@@ -1217,9 +1306,9 @@ __global__ __launch_bounds__(256) void DELTA_KERNEL(const bf16_t* o, const bf16_
     }
 }
 
-// workspace layout: [0,64) error word, diagnostics | [256, +32 slots) counters | [.., +4 slots) XCC ids | tiles from the next 4 KiB boundary
-static long long bwd_chain_xcc_off(long long slots) { return 256 + slots * 32; }
-static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 36 + 4095) & ~4095LL; }
+// workspace layout: [0,64) error word, diagnostics | [256, +64 slots) counters (ready[8] | consumed[8] per slot) | [.., +4 slots) XCC ids | tiles from the next 4 KiB boundary
+static long long bwd_chain_xcc_off(long long slots) { return 256 + slots * 64; }
+static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 68 + 4095) & ~4095LL; }
 static long long bwd_chain_ws_bytes(long long slots) { return bwd_chain_tiles_off(slots) + slots * (long long)(CH_R * 16384); }
 static int g_bwd_slots = 0;      // persistent grid: one workgroup per CU, a multiple of 8
 // chain length: VT_BWD_CHAIN (1 = off), default 2 (measured best: see the header comment).  The persistent grid is one workgroup per CU (the kernel's 145 KiB

@@ -25,6 +25,18 @@
 #define GB_BN 256
 #define GB_BK 64
 #define GB_STAGE 65536      // A 32 KiB | W 32 KiB
+#ifndef GB_LOADERS
+#define GB_LOADERS 0        // 1 = four extra waves (one per SIMD) do nothing but issue the LDS-DMA pieces: an LDS-DMA piece costs its
+#endif                      // issuing wave 100-185 cycles inside an MFMA phase (8 per K-tile per wave = as much as the MFMAs themselves).
+                            // NOT usable as written: three waves per SIMD cap a wave at 168 registers and the 128 accumulators + two
+                            // fragment sets spill (816 dwords)
+#ifndef GB_STAGGER
+#define GB_STAGGER 1         // 1: waves 4..7 issue their LDS-DMA pieces in the middle of the K-tile, waves 0..3 at its start: the two waves
+#endif                      // of a SIMD are then never both busy issuing DMA (the issue cost of one hides under the MFMAs of the other): +2-5 %.
+                            // 2: one piece per k-step, interleaved with the MFMAs -- measured 10 % SLOWER than 1.
+                            // Ablations (wrong results, timing only; M=35552 N=5760 K=1984): no operand traffic after the first
+                            // K-tile 1404 TF/s, no barrier 1092, neither 1484, shipped 1032 -- staging, not the MFMA loop, is the limit
+#define GB_THREADS (GB_LOADERS ? 768 : 512)
 #define GB_CS_LD 260        // fp32 row stride of the epilogue staging slab (32 rows x 260 floats = 32.5 KiB)
 
 typedef int gb_i32x4 __attribute__((ext_vector_type(4)));
@@ -68,7 +80,7 @@ __device__ __forceinline__ GbTile gb_tile(const GemmParams& p, int id, int nbm, 
 // K-tile of the current one is multiplied and its epilogue runs, so neither a workgroup launch nor the first HBM round
 // trip of a tile is exposed.
 template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
+__global__ __launch_bounds__(GB_THREADS, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * GB_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,35 +99,43 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     // period) and the same physical chunk, and (row >> 1) & 7 is distinct over the 8 same-parity rows of every group.
     // (row & 7, the 16-row-fragment swizzle of gemm_bf16.hip, gave 47 % conflict cycles here: rows 12 and 20 collide.)
     const int drl = lane >> 3, dcp = lane & 7;
-    int a_voff[4], w_voff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 8 * (wave + 8 * j) + drl;
-        const int sw = (row >> 1) & 7;
-        a_voff[j] = row * p.lda * 2 + ((dcp ^ sw) << 4);
-        w_voff[j] = row * p.ldw * 2 + ((dcp ^ sw) << 4);
-    }
-    auto dma = [&](const GbTile& t, int kt, int buf) {
+#if GB_LOADERS
+    const bool loader = wave >= 8;                 // waves 8..11: one per SIMD, 8 pieces of A and 8 of W per K-tile each
+    constexpr int NP = 8, PSTRIDE = 4;
+    const int pw = wave & 3;
+#else
+    constexpr bool loader = true;                  // every wave moves 4 pieces of A and 4 of W per K-tile itself
+    constexpr int NP = 4, PSTRIDE = 8;
+    const int pw = wave;
+#endif
+    // piece j of this wave is block pw + PSTRIDE j = rows 8 (pw + PSTRIDE j) + drl: swz(row) does not depend on j (8 PSTRIDE j / 2
+    // is a multiple of 8), so one per-lane offset serves all pieces and the row step goes into the scalar offset
+    const int row0p = 8 * pw + drl;
+    const int sw = (row0p >> 1) & 7;
+    const int a_voff0 = row0p * p.lda * 2 + ((dcp ^ sw) << 4);
+    const int w_voff0 = row0p * p.ldw * 2 + ((dcp ^ sw) << 4);
+    const int a_pstep = 8 * PSTRIDE * p.lda * 2, w_pstep = 8 * PSTRIDE * p.ldw * 2;
+    auto dma = [&](const GbTile& t, int kt, int buf, int j0 = 0, int j1 = NP) {
         const int soff = kt * GB_BK * 2;
         __amdgpu_buffer_rsrc_t ra = make_rsrc(t.a, t.a_bytes), rw = make_rsrc(t.w, t.w_bytes);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            char* dst = smem + buf * GB_STAGE + (wave + 8 * j) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, a_voff[j], soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 32768), 16, w_voff[j], soff, 0, 0);
+        for (int j = j0; j < j1; ++j) {
+            char* dst = smem + buf * GB_STAGE + (pw + PSTRIDE * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, a_voff0, soff + j * a_pstep, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 32768), 16, w_voff0, soff + j * w_pstep, 0, 0);
         }
     };
     // the same transfer through inline asm, for the cross-tile prefetch: the compiler orders every later LDS access behind
     // an LDS-DMA it knows about, which would park the whole epilogue behind the fetch.  Safe: it is older than every memory
     // operation of the epilogue (vmcnt retires in order, so each wait the compiler computes there also covers it), and the
     // next tile starts with a full barrier (vmcnt(0)).
-    auto dma_hidden = [&](const GbTile& t, int buf) {
+    auto dma_hidden = [&](const GbTile& t, int buf, int j0 = 0, int j1 = NP) {
         const gb_i32x4 ra = gb_words(t.a, t.a_bytes), rw = gb_words(t.w, t.w_bytes);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned dst = smem_lds + buf * GB_STAGE + (wave + 8 * j) * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst), "v"(a_voff[j]), "s"(ra) : "memory");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(dst + 32768), "v"(w_voff[j]), "s"(rw) : "memory");
+        for (int j = j0; j < j1; ++j) {
+            const unsigned dst = smem_lds + buf * GB_STAGE + (pw + PSTRIDE * j) * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(a_voff0), "s"(ra), "s"(j * a_pstep) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst + 32768), "v"(w_voff0), "s"(rw), "s"(j * w_pstep) : "memory");
         }
     };
 
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
     if (slot >= ntiles) return;
     GbTile cur = gb_tile(p, slot, nbm, nbn);
     int buf = 0;
-    dma(cur, 0, 0);
+    if (loader) dma(cur, 0, 0);
     for (int tile = slot; tile < ntiles; tile += gridDim.x) {
         const bool has_next = tile + (int)gridDim.x < ntiles;
         GbTile nxt = cur;
@@ -148,26 +168,47 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
         __syncthreads();                  // vmcnt(0): the first K-tile (fetched during the previous tile) has landed
         for (int kt = 0; kt < nk; ++kt) {
             const bool last = kt + 1 == nk;
-            if (!last) dma(cur, kt + 1, buf ^ 1);
-            else if (has_next) dma_hidden(nxt, buf ^ 1);
-            const char* As = smem + buf * GB_STAGE + (wm * 128 + fr) * 128;
-            const char* Ws = smem + buf * GB_STAGE + 32768 + (wn * 64 + fr) * 128;
+            // GB_STAGGER 2: one piece of A and one of W per k-step; waves 0..3 issue theirs before the k-step's MFMAs, waves
+            // 4..7 (the other wave of each SIMD) half-way through them, so a SIMD never has both of its waves blocked on DMA issue
+            auto issue = [&](int j0, int j1) {
+#ifndef GB_ABL_NODMA      // timing-only ablation: no operand traffic after the first K-tile (results wrong)
+                if (loader) {
+                    if (!last) dma(cur, kt + 1, buf ^ 1, j0, j1);
+                    else if (has_next) dma_hidden(nxt, buf ^ 1, j0, j1);
+                }
+#endif
+            };
+            const bool late = GB_STAGGER && !GB_LOADERS && wave >= 4;
+            if (GB_STAGGER < 2 && !late) issue(0, NP);
+#if GB_LOADERS
+            if (!loader)
+#endif
+            {
+                const char* As = smem + buf * GB_STAGE + (wm * 128 + fr) * 128;
+                const char* Ws = smem + buf * GB_STAGE + 32768 + (wn * 64 + fr) * 128;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int coff = (((ks * 2 + fh) ^ fx) << 4);
-                bf16x8 af[4], wf[2];
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (GB_STAGGER == 1 && ks == 2 && late) issue(0, NP);
+                    if (GB_STAGGER == 2 && !late) issue(ks, ks + 1);
+                    const int coff = (((ks * 2 + fh) ^ fx) << 4);
+                    bf16x8 af[4], wf[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(As + t * 4096 + coff);
+                    for (int t = 0; t < 4; ++t) af[t] = *(const bf16x8*)(As + t * 4096 + coff);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) wf[t] = *(const bf16x8*)(Ws + t * 4096 + coff);
+                    for (int t = 0; t < 2; ++t) wf[t] = *(const bf16x8*)(Ws + t * 4096 + coff);
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+                    for (int tm = 0; tm < 4; ++tm) {
+                        if (GB_STAGGER == 2 && late && tm == 2) issue(ks, ks + 1);
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                        for (int tn = 0; tn < 2; ++tn)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+                    }
+                }
             }
-            if (!last) __syncthreads();   // its vmcnt(0) also retires the next K-tile's LDS-DMA
+#ifndef GB_ABL_NOBAR      // timing-only ablation: no barrier between K-tiles (results wrong)
+            if (!last) __syncthreads();   // its vmcnt(0) also retires the next K-tile's LDS-DMA (in the waves that issued it)
             else gb_lds_barrier();        // the cross-tile prefetch keeps flying
+#endif
             buf ^= 1;
         }
 
@@ -181,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
         }
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
-            if (wm == (slab >> 2)) {
+            if (wave < 8 && wm == (slab >> 2)) {
                 const int tm = slab & 3;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
@@ -197,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_BIG_KERNEL(GemmParams p) {
             for (int pass = 0; pass < 4; ++pass) {
                 const int ml = pass * 8 + er;
                 const int m = cur.row0 + slab * 32 + ml;
-                if (m < p.M && n < p.N) {
+                if (wave < 8 && m < p.M && n < p.N) {
                     const f32x4 v = *(const f32x4*)(Cs + ml * GB_CS_LD + ec);
                     gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
                 }
@@ -219,7 +260,7 @@ static int VT_CAT(launch_big, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
     }
     const int ntiles = nbm * nbn;
     const int grid = ntiles < slots ? (ntiles + 7) / 8 * 8 : slots;
-    hipLaunchKernelGGL((GEMM_BIG_KERNEL<EPI, F32>), dim3(grid), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((GEMM_BIG_KERNEL<EPI, F32>), dim3(grid), dim3(GB_THREADS), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -49,7 +49,8 @@ int vt_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ld
                  const void* R, int ldr, int r_mod,
                  const float* gate_txt, const float* gate_vid, int gate_bstride, int S, int St,
                  void* C2, int ldc2, const void* U, int ldu, void* stream);
-/* tile selection of vt_gemm_bf16: 0 = by shape (default), 1 = always the 128x128 kernel, 2 = always the 256x256 kernel */
+/* tile selection of vt_gemm_bf16: 0 = by shape (default), 1 = always the 128x128 kernel, 2 = always the 256x256 kernel,
+ * 3 = always the 256x128 producer/consumer kernel */
 int vt_gemm_set_tile(int mode);
 
 /* Weight-gradient GEMM: C[P,Q] (+)= alpha * sum_m A[m,P] * B[m,Q]  (A = dY [M,lda], B = X [M,ldb] bf16, C fp32).

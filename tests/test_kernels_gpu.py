@@ -28,7 +28,7 @@ def close(a, b, rtol, atol, what=""):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+@pytest.fixture(params=[1, 2, 3], ids=["tile128", "tile256", "tile256x128_pc"])
 def gemm_tile(request):
     """both tilings of vt_gemm_bf16 (the library picks by shape; the tests force each one on every shape)"""
     from vt355 import ops

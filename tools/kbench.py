@@ -56,7 +56,7 @@ def main():
                                 (S, 1984, 5760, "dqkv"), (4096, 4096, 4096, "sq4k"), (8192, 8192, 8192, "sq8k")]:
             a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
             out = torch.empty(M, N, dtype=BF, device=dev); b = torch.zeros(N, dtype=BF, device=dev)
-            for mode, tag in ((1, "tile128"), (2, "tile256")):
+            for mode, tag in ((1, "tile128"), (2, "tile256"), (3, "tile_pc ")):
                 ops.gemm_set_tile(mode)
                 med, mn = timeit(lambda: ops.gemm(a, w, out, b))
                 tf = 2.0 * M * N * K / med / 1e9

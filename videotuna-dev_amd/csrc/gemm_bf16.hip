@@ -200,21 +200,27 @@ static bool VT_CAT(al16, VT_SUFFIX)(const void* p) { return (((uintptr_t)p) & 15
 
 // 256x256-tile kernel (gemm_big_bf16.hip) for the token-sized problems; 0 = choose by shape, 1 = always 128x128, 2 = always 256x256
 int VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(const GemmParams& p, int epilogue, int out_fp32, hipStream_t st);
+int VT_CAT(vt_gemm_pc_dispatch, VT_SUFFIX)(const GemmParams& p, int epilogue, int out_fp32, hipStream_t st);     // gemm_pc_bf16.hip
 static int VT_CAT(g_gemm_tile, VT_SUFFIX) = 0;
 extern "C" int VT_CAT(vt_gemm_set_tile, VT_SUFFIX)(int mode) {
-    if (mode < 0 || mode > 2) return VT_ERR_BAD_SHAPE;
+    if (mode < 0 || mode > 3) return VT_ERR_BAD_SHAPE;
     VT_CAT(g_gemm_tile, VT_SUFFIX) = mode;
     return VT_OK;
 }
-static bool VT_CAT(use_big, VT_SUFFIX)(int M, int N, int K) {
+// which tiling: 1 = 128x128 (this file), 2 = 256x256 (gemm_big_bf16.hip), 3 = 256x128 producer/consumer (gemm_pc_bf16.hip).
+// r01 measurements (tools/kbench.py gemm), TF/s for 128^2 / 256^2 / producer-consumer:
+//   M=35552: N=5760 K=1984  828 / 1012 / 1025 | N=7680 K=1920 978 / 1099 / 1048 | N=1920 K=7680 925 /  999 / 1104
+//            N=1984 K=5760  938 / 1042 / 1085 | N=1920 K=1984 957 /  913 /  975 | N=1984 K=1920 931 /  961 /  983
+//   M=17776: N=5760 1015 / 1034 / 1043 | N=7680 968 / 1061 / 1024 | N=1920 K=7680 918 / 875 / 1018 | N=1984 K=5760 951 / 917 / 996
+//            N=1920 K=1984 901 / 825 / 907        8192^3: 1050 / 1236 / 1211
+static int VT_CAT(pick_tile, VT_SUFFIX)(int M, int N, int K) {
     const int mode = VT_CAT(g_gemm_tile, VT_SUFFIX);
-    if (mode) return mode == 2;
-    // r01 measurements (tools/kbench.py gemm), 128x128 -> 256x256 tile, TF/s:
-    //   M=35552: N=5760 K=1984 851 -> 1028 | N=7680 K=1920 986 -> 1121 | N=1920 K=7680 933 -> 1039 | N=1984 K=5760 941 -> 1044
-    //            N=1920 K=1984 968 ->  920 (7.5 column tiles round up to 8; short K loop)
-    //   M=17776: N=5760 1007 -> 1048 | N=7680 962 -> 1072 | N=1920 K=7680 918 -> 900 | N=1984 K=5760 975 -> 913
-    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
-    return (N >= 4096 && tiles >= 512) || (K >= 4096 && tiles >= 1024);
+    if (mode) return mode;
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const long long tpc = (long long)((M + 255) / 256) * ((N + 127) / 128);
+    if (N >= 6144 && t256 >= 512) return 2;
+    if (tpc >= 512 && K >= 512) return 3;
+    return 1;
 }
 
 extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
@@ -232,7 +238,14 @@ extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldc2 = ldc2; p.ldu = ldu;
     p.S = S > 0 ? S : 1; p.St = St; p.gate_bstride = gate_bstride; p.r_mod = r_mod;
     hipStream_t st = (hipStream_t)stream;
-    const bool big = VT_CAT(use_big, VT_SUFFIX)(M, N, K);
+    const int tile = VT_CAT(pick_tile, VT_SUFFIX)(M, N, K);
+    const bool big = tile == 2;
+    if (tile == 3) {                                     // producer / consumer kernel (256x128 tile)
+        if (epilogue == EPI_BIAS_GELU && (out_fp32 || C2 == nullptr || (ldc2 % 4) || !VT_CAT(al16, VT_SUFFIX)(C2))) return VT_ERR_BAD_SHAPE;
+        if (epilogue == EPI_GATED_RES && (out_fp32 || R == nullptr || (ldr % 4) || !VT_CAT(al16, VT_SUFFIX)(R))) return VT_ERR_BAD_SHAPE;
+        if (epilogue == EPI_DGELU && (out_fp32 || U == nullptr || (ldu % 4) || !VT_CAT(al16, VT_SUFFIX)(U))) return VT_ERR_BAD_SHAPE;
+        return VT_CAT(vt_gemm_pc_dispatch, VT_SUFFIX)(p, epilogue, out_fp32, st);
+    }
     switch (epilogue) {
         case EPI_BIAS:
             if (big) return VT_CAT(vt_gemm_big_dispatch, VT_SUFFIX)(p, epilogue, out_fp32, st);

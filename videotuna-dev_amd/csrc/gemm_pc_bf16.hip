@@ -1,0 +1,235 @@
+// bf16 MFMA GEMM for gfx950, producer / consumer version:  C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue), fp32 accumulate.
+//
+// Same contract and epilogues as gemm_bf16.hip / gemm_big_bf16.hip (the nn.Linear layers of diffusers' CogVideoXBlock reached
+// through videotuna/models/cogvideo_hf/cogvideo_pl.py:865-871, SURVEY 8(a) a4,a5).
+//
+// Why: the ablations of the 256x256 kernel (gemm_big_bf16.hip) show its MFMA / LDS-read loop running at 1.4-1.8 PFLOP/s once
+// the operand staging is taken away and at 1.0-1.25 with it -- an LDS-DMA piece (1 KiB) blocks the wave that issues it for
+// 100-185 cycles inside an MFMA phase, and every wave issues 8 of them per K-tile.  Here the two jobs are separate waves:
+//   * waves 0..3 (one per SIMD) only multiply: 256x128 workgroup tile, 128x64 per wave = 4x2 tiles of
+//     v_mfma_f32_32x32x16_bf16 (128 accumulator registers), fragments of the next k-step fetched while the current one is
+//     multiplied;
+//   * waves 4..7 (one per SIMD) only move data: 12 LDS-DMA pieces per K-tile each (8 of A, 4 of W), always two K-tiles
+//     ahead of the multipliers in a THREE-stage ring (3 x 48 KiB), waiting with a counted vmcnt that leaves the newest
+//     K-tile in flight.
+// One barrier per K-tile hands a landed stage to the multipliers and a consumed one back to the loaders.  The kernel is
+// persistent (one workgroup per CU) and the ring runs straight across output tiles: while the multipliers run the epilogue
+// of tile T, the first two K-tiles of tile T+1 are already landing.
+#include "gemm_epilogue.h"
+
+#ifndef VT_SUFFIX
+#define VT_SUFFIX
+#endif
+#define VT_CAT_(a, b) a##b
+#define VT_CAT(a, b) VT_CAT_(a, b)
+#define GEMM_PC_KERNEL VT_CAT(gemm_tn_pc_kernel, VT_SUFFIX)
+
+#define GP_BM 256
+#define GP_BN 128
+#define GP_BK 64
+#define GP_STAGE 49152      // A 32 KiB | W 16 KiB
+#define GP_NS 3
+#define GP_CS_LD 132        // fp32 row stride of the epilogue staging slab (32 rows x 132 floats = 16.5 KiB)
+
+static __device__ __forceinline__ void gp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct GpTile {
+    int row0, col0;
+    const bf16_t* a;
+    const bf16_t* w;
+    unsigned a_bytes, w_bytes;
+};
+
+static __device__ __forceinline__ GpTile gp_tile(const GemmParams& p, int id, int nbm, int nbn) {
+    // grouped ordering (4 row-tiles per group, column-tiles outer): the 32 workgroups of an XCD that run together share
+    // A row-panels / W column-panels in its L2
+    const int GM = 4;
+    const int in_group = GM * nbn;
+    const int group = id / in_group;
+    const int first_m = group * GM;
+    const int gsz = min(nbm - first_m, GM);
+    GpTile t;
+    t.row0 = (first_m + (id % in_group) % gsz) * GP_BM;
+    t.col0 = ((id % in_group) / gsz) * GP_BN;
+    const long long a_rem = (long long)(p.M - t.row0) * p.lda * 2;
+    const long long w_rem = (long long)(p.N - t.col0) * p.ldw * 2;
+    t.a = p.A + (size_t)t.row0 * p.lda;
+    t.w = p.W + (size_t)t.col0 * p.ldw;
+    t.a_bytes = (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem);
+    t.w_bytes = (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem);
+    return t;
+}
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[GP_NS * GP_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int nbm = (p.M + GP_BM - 1) / GP_BM, nbn = (p.N + GP_BN - 1) / GP_BN;
+    const int ntiles = nbm * nbn;
+    const int spx = gridDim.x >> 3;
+    const int slot = (int)(blockIdx.x & 7) * spx + (int)(blockIdx.x >> 3);
+    const int nk = p.K / GP_BK;
+    if (slot >= ntiles) return;
+    const int my_tiles = (ntiles - slot + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_kt = my_tiles * nk;          // K-tiles this workgroup streams, over all its output tiles
+
+    if (loader) {
+        // =================================== loader waves ===================================
+        // A K-tile of A is 32 pieces of 1 KiB (8 rows x 128 B), of W 16; wave lw moves pieces lw, lw+4, ...  Lane l lands at
+        // (row l>>3, physical chunk l&7) and fetches logical chunk (l&7) ^ swz(row), swz(row) = (row>>1)&7 (conflict-free
+        // 32-row fragment reads, see gemm_big_bf16.hip); the piece step (32 rows) does not change swz, so it is a scalar offset.
+        const int lw = wave - 4;
+        const int drl = lane >> 3, dcp = lane & 7;
+        const int row0p = 8 * lw + drl;
+        const int sw = (row0p >> 1) & 7;
+        const int a_voff0 = row0p * p.lda * 2 + ((dcp ^ sw) << 4);
+        const int w_voff0 = row0p * p.ldw * 2 + ((dcp ^ sw) << 4);
+        const int a_pstep = 32 * p.lda * 2, w_pstep = 32 * p.ldw * 2;
+        GpTile cur = gp_tile(p, slot, nbm, nbn);
+        int tile = slot, kt = 0;
+        auto issue = [&](int g) {                // K-tile number g of the stream -> stage g % 3
+            __amdgpu_buffer_rsrc_t ra = make_rsrc(cur.a, cur.a_bytes), rw = make_rsrc(cur.w, cur.w_bytes);
+            const int soff = kt * GP_BK * 2;
+            char* st = smem + (g % GP_NS) * GP_STAGE + lw * 1024;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + j * 4096), 16, a_voff0, soff + j * a_pstep, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 32768 + j * 4096), 16, w_voff0, soff + j * w_pstep, 0, 0);
+            if (++kt == nk) {                    // next K-tile belongs to the next output tile
+                kt = 0;
+                tile += gridDim.x;
+                if (tile < ntiles) cur = gp_tile(p, tile, nbm, nbn);
+            }
+        };
+        int issued = 0;
+        for (; issued < 2 && issued < total_kt; ++issued) issue(issued);
+        for (int g = 0; g < total_kt; ++g) {
+            // K-tile g must have landed before the barrier that hands it to the multipliers; K-tile g+1 may stay in flight
+            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            gp_barrier();                        // (A) stage g % 3 is ready / stage (g-1) % 3 has been consumed
+            const bool tile_end = (g + 1) % nk == 0;
+            if (tile_end) {
+                // the multipliers stage their accumulators through stage g % 3 ... (g+2) % 3 are not touched; mirror their barriers
+#pragma unroll 1
+                for (int i = 0; i < 17; ++i) gp_barrier();
+            }
+            if (issued < total_kt) { issue(issued); ++issued; }      // into stage (g+2) % 3 = (g-1) % 3: consumed before barrier (A)
+        }
+        return;
+    }
+
+    // =================================== multiplier waves ===================================
+    const int wm = wave & 1, wn = wave >> 1;                  // 2 x 2 waves: rows 128 wm .., columns 64 wn ..
+    const int fr = lane & 31;             // row inside a 32-row fragment
+    const int fh = lane >> 5;             // which 8-element half of a 16-deep k-step
+    const int fx = (fr >> 1) & 7;         // swz(row)
+    const int er = tid >> 5;              // epilogue (256 threads): 0..7, row inside an 8-row pass
+    const int ec = (tid & 31) * 4;        // first of this thread's 4 columns
+    int g = 0;
+    for (int tile = slot; tile < ntiles; tile += gridDim.x) {
+        const GpTile cur = gp_tile(p, tile, nbm, nbn);
+        // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
+        // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            gp_barrier();                    // (A) the loaders have landed stage g % 3
+            const char* As = smem + (g % GP_NS) * GP_STAGE + (wm * 128 + fr) * 128;
+            const char* Ws = smem + (g % GP_NS) * GP_STAGE + 32768 + (wn * 64 + fr) * 128;
+            bf16x8 af[2][4], wf[2][2];       // fragments of k-step ks in [ks & 1]: the next ones load under the current MFMAs
+            auto frags = [&](int ks) {
+                const int coff = (((ks * 2 + fh) ^ fx) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) af[ks & 1][t] = *(const bf16x8*)(As + t * 4096 + coff);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[ks & 1][t] = *(const bf16x8*)(Ws + t * 4096 + coff);
+            };
+            frags(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) frags(ks + 1);
+                // keep the six LDS reads of the next k-step ahead of this k-step's eight MFMAs (left alone, the scheduler sinks
+                // them to just before their use and a lone wave then waits out the LDS latency twice per k-step)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][tn], af[ks & 1][tm], acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---------------- epilogue: eight 32-row slabs through the stage that was just consumed (17 barriers) ----------------
+        float* Cs = (float*)(smem + ((g - 1) % GP_NS) * GP_STAGE);
+        const int n = cur.col0 + ec;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n < p.N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+        }
+        gp_barrier();                        // every multiplier is done reading the stage (the loaders mirror this one too)
+#pragma unroll
+        for (int slab = 0; slab < 8; ++slab) {
+            if (wm == (slab >> 2)) {
+                const int tm = slab & 3;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = wn * 64 + tn * 32 + 8 * q + 4 * fh;
+                        *(f32x4*)(Cs + fr * GP_CS_LD + nl) =
+                            (f32x4){acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+                    }
+            }
+            gp_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int ml = pass * 8 + er;
+                const int m = cur.row0 + slab * 32 + ml;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = *(const f32x4*)(Cs + ml * GP_CS_LD + ec);
+                    gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
+                }
+            }
+            gp_barrier();
+        }
+    }
+}
+
+template <int EPI, bool F32>
+static int VT_CAT(launch_pc, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
+    const int nbm = (p.M + GP_BM - 1) / GP_BM, nbn = (p.N + GP_BN - 1) / GP_BN;
+    static int slots = 0;                 // persistent grid: one workgroup per CU, a multiple of 8
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        slots = cus >= 8 ? cus / 8 * 8 : 8;
+    }
+    const int ntiles = nbm * nbn;
+    const int grid = ntiles < slots ? (ntiles + 7) / 8 * 8 : slots;
+    hipLaunchKernelGGL((GEMM_PC_KERNEL<EPI, F32>), dim3(grid), dim3(512), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// same validation as vt_gemm_bf16 (gemm_bf16.hip), which calls this when the producer / consumer tiling is selected
+int VT_CAT(vt_gemm_pc_dispatch, VT_SUFFIX)(const GemmParams& p, int epilogue, int out_fp32, hipStream_t st) {
+    switch (epilogue) {
+        case EPI_BIAS:
+            return out_fp32 ? VT_CAT(launch_pc, VT_SUFFIX)<EPI_BIAS, true>(p, st) : VT_CAT(launch_pc, VT_SUFFIX)<EPI_BIAS, false>(p, st);
+        case EPI_BIAS_GELU: return VT_CAT(launch_pc, VT_SUFFIX)<EPI_BIAS_GELU, false>(p, st);
+        case EPI_GATED_RES: return VT_CAT(launch_pc, VT_SUFFIX)<EPI_GATED_RES, false>(p, st);
+        case EPI_DGELU: return VT_CAT(launch_pc, VT_SUFFIX)<EPI_DGELU, false>(p, st);
+        default: return VT_ERR_UNSUPPORTED;
+    }
+}

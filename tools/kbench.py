@@ -44,7 +44,7 @@ def main():
         M, N, K = 2 * S, 5760, 1984
         a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
         out = torch.empty(M, N, dtype=BF, device=dev); b = torch.zeros(N, dtype=BF, device=dev)
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             ops.gemm_set_tile(mode)
             for _ in range(4):
                 ops.gemm(a, w, out, b)

@@ -10,6 +10,7 @@
 // 128x128 output tile per workgroup, 4 waves (2x2) x 4x4 tiles of v_mfma_f32_16x16x32_bf16, 64 tokens per K-tile,
 // double-buffered.  Tokens past M read zeros (buffer bounds check).  P and Q must be multiples of 128.
 #include "common.h"
+#include <cstdlib>
 
 struct GemmNtParams {
     const bf16_t* A;   // [M, lda]  (dY)
@@ -18,6 +19,8 @@ struct GemmNtParams {
     int M, P, Q, lda, ldb, ldc;
     int accumulate;    // 1: C += result, 0: C = result
     float alpha;
+    int splits;        // > 1: the token axis is cut into `splits` ranges of m_chunk tokens (blockIdx.y), partial tiles are added
+    int m_chunk;       //      to C with fp32 atomics (C already holds the value to accumulate onto, or zeros)
 };
 
 typedef __attribute__((ext_vector_type(8))) short short8nt;
@@ -43,9 +46,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
     const int tile_p = id % nbp, tile_q = id / nbp;
     const int p0 = tile_p * 128, q0 = tile_q * 128;
 
-    const long long a_bytes = (long long)p.M * p.lda * 2, b_bytes = (long long)p.M * p.ldb * 2;
-    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + p0, (unsigned)((a_bytes - p0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (a_bytes - p0 * 2)));
-    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + q0, (unsigned)((b_bytes - q0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (b_bytes - q0 * 2)));
+    // this workgroup's token range (split-K over the token axis: dW has few output tiles -- 675 for the fused QKV weight --
+    // and a 35 552-long reduction, so one workgroup per tile leaves a third of the chip idle in the last round)
+    const int m_lo = (int)blockIdx.y * p.m_chunk;
+    const int m_cnt = min(p.M - m_lo, p.m_chunk);
+    const bf16_t* Ab = p.A + (size_t)m_lo * p.lda;
+    const bf16_t* Bb = p.B + (size_t)m_lo * p.ldb;
+    const long long a_bytes = (long long)m_cnt * p.lda * 2, b_bytes = (long long)m_cnt * p.ldb * 2;
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab + p0, (unsigned)((a_bytes - p0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (a_bytes - p0 * 2)));
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb + q0, (unsigned)((b_bytes - q0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (b_bytes - q0 * 2)));
 
     // LDS-DMA: a tile is 64 rows x 256 B = 16 blocks of 1 KiB (4 rows each); wave w moves blocks w, w+4, w+8, w+12 of A and B.
     // lane l lands at (row l>>4, physical chunk l&15) -> it fetches logical chunk (l&15) ^ swz(row).
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.M + 63) / 64;
+    const int nk = (m_cnt + 63) / 64;
     dma(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -119,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
                 const int qc = q0 + wq * 64 + tq * 16 + fr;
                 float* c = p.C + (size_t)pr * p.ldc + qc;
                 const float v = p.alpha * acc[tp][tq][rg];
-                *c = p.accumulate ? (*c + v) : v;
+                if (p.splits > 1) atomicAdd(c, v);
+                else *c = p.accumulate ? (*c + v) : v;
             }
 }
 
@@ -129,7 +139,31 @@ extern "C" int vt_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, f
         return VT_ERR_BAD_SHAPE;
     if ((long long)M * lda * 2 >= 0x7fffffffLL || (long long)M * ldb * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return VT_ERR_BAD_ALIGN;
-    GemmNtParams p{(const bf16_t*)A, (const bf16_t*)B, C, M, P, Q, lda, ldb, ldc, accumulate, alpha};
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((P / 128) * (Q / 128)), dim3(256), 0, (hipStream_t)stream, p);
+    GemmNtParams p{(const bf16_t*)A, (const bf16_t*)B, C, M, P, Q, lda, ldb, ldc, accumulate, alpha, 1, M};
+    // split the token axis so that the grid fills whole rounds of the chip (2 workgroups per CU); ranges stay >= 2048 tokens
+    const int tiles = (P / 128) * (Q / 128);
+    static int wg_slots = 0;
+    if (wg_slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        wg_slots = cus > 0 ? 2 * cus : 512;
+    }
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= 8; ++sp) {
+        if (sp > 1 && M / sp < 2048) break;
+        const long long wgs = (long long)tiles * sp;
+        const double eff = (double)wgs / (double)(((wgs + wg_slots - 1) / wg_slots) * wg_slots);
+        if (eff > best_eff + 0.03) { best_eff = eff; best = sp; }
+    }
+    if (const char* e = getenv("VT_NT_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= 16) best = v; }
+    p.splits = best;
+    p.m_chunk = ((M + best - 1) / best + 63) / 64 * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (best > 1 && !accumulate) {
+        // partial tiles are ADDED: start from zeros
+        if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)Q * 4, (size_t)P, st) != hipSuccess) return VT_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((P / 128) * (Q / 128), best), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -67,6 +67,22 @@ def main():
                 pre = torch.empty(M, N, dtype=BF, device=dev)
                 med, mn = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))
                 print(f"   +gelu epilogue: {med:.3f} ms {2.0*M*N*K/med/1e9:.0f} TF/s", flush=True)
+    if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
+        M = 2 * S
+        x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)
+        o1 = torch.zeros(4, d, device=dev); o2 = torch.zeros(4, d, device=dev)
+        mean = torch.zeros(M, device=dev); rstd = torch.ones(M, device=dev)
+        med, _ = timeit(lambda: ops.group_colsum(x, o1, D=d))
+        print(f"group_colsum plain  M={M} D={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        med, _ = timeit(lambda: ops.group_colsum(x, o1, y=y, out2=o2, mean=mean, rstd=rstd, D=d, S=S, St=226, grouped=True))
+        print(f"group_colsum LN-grouped M={M} D={d}: {med*1e3:.1f} us  {2*M*d*2/med/1e6:.0f} GB/s", flush=True)
+        t4 = torch.randn(M, 64, device=dev).to(BF)
+        ob = torch.zeros(d * 4, device=dev)
+        med, _ = timeit(lambda: ops.skinny_tn(x, t4, 4, ob, 4, 1, 0.25, d))
+        print(f"skinny_tn R=4  M={M} P={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        oa = torch.zeros(12 * d, device=dev)
+        med, _ = timeit(lambda: ops.skinny_tn(x, t4, 12, oa, 1, d, 1.0, d))
+        print(f"skinny_tn R=12 M={M} P={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
     if "nt" in which:
         for (M, P, Q, name) in [(S, 5760, 1920, "dW_qkv"), (S, 7680, 1920, "dW_ff1"), (S, 1920, 7680, "dW_ff2"), (2 * S, 5760, 1920, "dW_qkv_B2")]:
             a = torch.randn(M, P, device=dev).to(BF); b = torch.randn(M, Q, device=dev).to(BF)

@@ -5,6 +5,7 @@
 // T = x A^T in 16 extra columns and the weight carries (alpha/r) * B there, so forward and dX need no
 // special GEMM; these kernels produce T, the rank-r gradients, and the rank-r correction of dX.
 #include "common.h"
+#include <cstdlib>
 
 // ---------------- T[M,16] = X[M,K] * A[R,K]^T  (R <= 16 rows valid, rest zero) -> bf16 ----------------
 // one wave per 16 rows, v_mfma_f32_16x16x32_bf16; each lane streams 32 contiguous bytes of its row per
@@ -59,7 +60,8 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
 // them in a fixed order (also bitwise reproducible); without a workspace the partials are added with atomics.
 // Columns: 512-wide blocks of 128 threads (4 columns = one 8-byte load per thread and row), rows of a slice walked 16 at
 // a time with all 16 loads in flight; the slice's Small rows are staged once in LDS as fp32.
-#define SK_SLICES 128
+#define SK_SLICES 96           // r01 (M=35552, P=1920, R=4): 32 / 64 / 96 / 128 / 192 / 256 / 512 slices -> 165 / 124 / 92 / 109 / 145 / 168 / 289 us:
+                               // fewer slices need several launches (512 staged rows per slice), more pile atomics onto the same P x R addresses
 #define SK_MAXROWS 512         // rows per slice that fit the LDS staging
 template <int RR>
 __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
@@ -147,11 +149,14 @@ extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds
     if (((uintptr_t)Big) & 7) return VT_ERR_BAD_ALIGN;
     if (workspace != nullptr && (((uintptr_t)workspace) & 15)) return VT_ERR_BAD_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const long long chunk = (long long)SK_SLICES * SK_MAXROWS;          // rows handled per launch
+    static int slices_env = -1;
+    if (slices_env < 0) { const char* e = getenv("VT_SK_SLICES"); slices_env = e ? atoi(e) : 0; }
+    const int nsl = (workspace == nullptr && slices_env > 0 && slices_env <= 1024) ? slices_env : SK_SLICES;
+    const long long chunk = (long long)nsl * SK_MAXROWS;          // rows handled per launch
     for (long long mbase = 0; mbase < M; mbase += chunk) {
         const long long mc = (M - mbase) < chunk ? (M - mbase) : chunk;
-        const int rps = (int)((mc + SK_SLICES - 1) / SK_SLICES);
-        dim3 grid((P + 511) / 512, SK_SLICES);
+        const int rps = (int)((mc + nsl - 1) / nsl);
+        dim3 grid((P + 511) / 512, nsl);
         const bf16_t* bg = (const bf16_t*)Big + (size_t)mbase * ldb;
         const bf16_t* smp = (const bf16_t*)Small + (size_t)mbase * lds_;
         if (R <= 4) {

@@ -10,8 +10,10 @@
 // Grid: (column blocks of 512, row slices); a block of 128 threads walks its slice 8 rows at a time (4 columns =
 // one 8-byte load per thread and row) and adds its partial sums with fp32 atomics (few slices -> few atomics).
 #include "common.h"
+#include <cstdlib>
 
-#define RD_SLICES 64
+#define RD_SLICES 256       // r01: 64 / 256 / 512 / 1024 slices -> 70 / 59 / 81 / 127 us plain, 147 / 75 / 131 / 217 us LayerNorm-grouped (M=35552, D=1920):
+                            // too few blocks starve the CUs (2 waves each), too many pile fp32 atomics onto the same 1920 addresses
 
 struct ReduceParams {
     const bf16_t* X; int ldx;
@@ -89,8 +91,13 @@ extern "C" int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, c
     if ((((uintptr_t)X) | ((uintptr_t)Y)) & 7) return VT_ERR_BAD_ALIGN;
     ReduceParams p{(const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, mean, rstd, out1, out2, M, D, S > 0 ? S : 1, St, grouped,
                    o_bstride, o_segstride, 0};
-    p.rows_per_slice = (int)((M + RD_SLICES - 1) / RD_SLICES);
-    dim3 grid((D + 511) / 512, RD_SLICES);
+    // slices: enough 128-thread blocks for ~12 waves per CU (the first version's 64 slices = 2 waves per CU read at 1.25 TB/s)
+    static int slices_env = -1;
+    if (slices_env < 0) { const char* e = getenv("VT_RD_SLICES"); slices_env = e ? atoi(e) : 0; }
+    int slices = slices_env > 0 ? slices_env : RD_SLICES;
+    if (slices > M) slices = (int)M;
+    p.rows_per_slice = (int)((M + slices - 1) / slices);
+    dim3 grid((D + 511) / 512, slices);
     hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(128), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -83,6 +83,10 @@ def main():
         oa = torch.zeros(12 * d, device=dev)
         med, _ = timeit(lambda: ops.skinny_tn(x, t4, 12, oa, 1, d, 1.0, d))
         print(f"skinny_tn R=12 M={M} P={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        med, _ = timeit(lambda: ops.skinny_tn(x, t4, 4, ob, 4, 1, 0.25, d, use_workspace=True))
+        print(f"skinny_tn R=4  copies M={M} P={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
+        med, _ = timeit(lambda: ops.skinny_tn(x, t4, 12, oa, 1, d, 1.0, d, use_workspace=True))
+        print(f"skinny_tn R=12 copies M={M} P={d}: {med*1e3:.1f} us  {M*d*2/med/1e6:.0f} GB/s", flush=True)
     if "nt" in which:
         for (M, P, Q, name) in [(S, 5760, 1920, "dW_qkv"), (S, 7680, 1920, "dW_ff1"), (S, 1920, 7680, "dW_ff2"), (2 * S, 5760, 1920, "dW_qkv_B2")]:
             a = torch.randn(M, P, device=dev).to(BF); b = torch.randn(M, Q, device=dev).to(BF)

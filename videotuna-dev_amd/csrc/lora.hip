@@ -60,8 +60,10 @@ extern "C" int vt_lora_down(const void* X, int ldx, const void* A, int lda, int 
 // them in a fixed order (also bitwise reproducible); without a workspace the partials are added with atomics.
 // Columns: 512-wide blocks of 128 threads (4 columns = one 8-byte load per thread and row), rows of a slice walked 16 at
 // a time with all 16 loads in flight; the slice's Small rows are staged once in LDS as fp32.
-#define SK_SLICES 96           // r01 (M=35552, P=1920, R=4): 32 / 64 / 96 / 128 / 192 / 256 / 512 slices -> 165 / 124 / 92 / 109 / 145 / 168 / 289 us:
-                               // fewer slices need several launches (512 staged rows per slice), more pile atomics onto the same P x R addresses
+#define SK_SLICES 192          // r01 (M=35552, P=1920): with the partial sums transposed through LDS (contiguous atomics) 96 / 192 / 384 slices
+                               // -> 49 / 35 / 37 us for R=4 (3.9 TB/s), 126 / 83 / 99 us for R=12; before the transpose every lane's 16 adds hit
+                               // 16 lines of their own and the kernel took 90-110 us whatever the slice count
+#define SK_COPIES 8
 #define SK_MAXROWS 512         // rows per slice that fit the LDS staging
 template <int RR>
 __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int ldb, const bf16_t* Small, int lds_, int R,
@@ -76,15 +78,15 @@ __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int l
         sm[i] = rr < R ? bf2f(Small[(size_t)(m0 + mm) * lds_ + rr]) : 0.f;
     }
     __syncthreads();
-    if (p >= P) return;
+    const bool valid = p < P;                    // (no early return: the epilogue below has block barriers)
     float acc[4][RR];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) acc[c][rr] = 0.f;
-    const bf16_t* bp = Big + (size_t)m0 * ldb + p;
+    const bf16_t* bp = Big + (size_t)m0 * ldb + (valid ? p : 0);
     int mb = 0;
-    for (; mb + 16 <= rows; mb += 16) {
+    for (; valid && mb + 16 <= rows; mb += 16) {
         u32x2 raw[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) raw[u] = *(const u32x2*)(bp + (size_t)(mb + u) * ldb);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int l
             }
         }
     }
-    for (; mb < rows; ++mb) {
+    for (; valid && mb < rows; ++mb) {
         u32x2 raw = *(const u32x2*)(bp + (size_t)mb * ldb);
         const float b0 = __uint_as_float(raw[0] << 16), b1 = __uint_as_float(raw[0] & 0xffff0000u);
         const float b2 = __uint_as_float(raw[1] << 16), b3 = __uint_as_float(raw[1] & 0xffff0000u);
@@ -116,19 +118,37 @@ __global__ __launch_bounds__(128) void skinny_tn_kernel(const bf16_t* Big, int l
         }
     }
     if (ws != nullptr) {
-        // partial tile of this slice: ws[slice][p][RR]  (16-byte stores, 4 rows of RR floats per thread)
-        float* w = ws + ((size_t)blockIdx.y * P + p) * RR;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r4 = 0; r4 < RR / 4; ++r4)
-                *(f32x4*)(w + c * RR + 4 * r4) = (f32x4){acc[c][4 * r4], acc[c][4 * r4 + 1], acc[c][4 * r4 + 2], acc[c][4 * r4 + 3]};
-    } else {
+        if (!valid) return;
+        // SK_COPIES zeroed copies of the [P, RR] result: slice s adds into copy s % SK_COPIES, so an address sees
+        // SK_SLICES / SK_COPIES adds instead of SK_SLICES (same-address fp32 atomics serialise at ~0.5 us each)
+        float* w = ws + ((size_t)(blockIdx.y % SK_COPIES) * P + p) * RR;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int rr = 0; rr < RR; ++rr)
-                if (rr < R) atomicAdd(out + (size_t)(p + c) * osp + (size_t)rr * osr, alpha * acc[c][rr]);
+                if (rr < R) atomicAdd(w + c * RR + rr, acc[c][rr]);
+    } else {
+        // A lane's 16 partial sums are 16 different cache lines for its neighbours' (a wave instruction = 64 lines with one
+        // dword each: ~17 G adds/s, 20x below the atomic units' rate).  Transpose through LDS so that every atomic instruction
+        // adds 64 CONSECUTIVE floats of the output: [p][r] order when the r index is the fast one (osr == 1), else [r][p].
+        __syncthreads();                                   // every thread of the block is done with the staged Small rows
+        const int pl = threadIdx.x * 4;                    // first of this thread's 4 columns inside the block's 512
+        const int pb0 = blockIdx.x * 512;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int rr = 0; rr < RR; ++rr) sm[(pl + c) * RR + rr] = alpha * acc[c][rr];     // 512 x RR floats <= SK_MAXROWS x RR
+        __syncthreads();
+        if (osr == 1) {
+            for (int i = threadIdx.x; i < 512 * RR; i += 128) {
+                const int pp = i / RR, rr = i - pp * RR;
+                if (rr < R && pb0 + pp < P) atomicAdd(out + (size_t)(pb0 + pp) * osp + rr, sm[i]);
+            }
+        } else {
+            for (int rr = 0; rr < R; ++rr)
+                for (int pp = threadIdx.x; pp < 512; pp += 128)
+                    if (pb0 + pp < P) atomicAdd(out + (size_t)(pb0 + pp) * osp + (size_t)rr * osr, sm[pp * RR + rr]);
+        }
     }
 }
 template <int RR>
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* ws, int
     for (int k = 0; k < nslices; ++k) s += ws[(size_t)k * P * RR + i];
     out[(size_t)p * osp + (size_t)rr * osr] += alpha * s;
 }
-extern "C" long long vt_skinny_tn_workspace_bytes(int P) { return (long long)SK_SLICES * P * 16 * 4; }
+extern "C" long long vt_skinny_tn_workspace_bytes(int P) { return (long long)SK_COPIES * P * 16 * 4; }
 extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds_, int R, float* out, long long osp,
                             long long osr, float alpha, long long M, int P, float* workspace, void* stream) {
     if (M <= 0 || P <= 0 || (P % 4) || R <= 0 || R > 16 || (ldb % 4)) return VT_ERR_BAD_SHAPE;
@@ -151,8 +171,10 @@ extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds
     hipStream_t st = (hipStream_t)stream;
     static int slices_env = -1;
     if (slices_env < 0) { const char* e = getenv("VT_SK_SLICES"); slices_env = e ? atoi(e) : 0; }
-    const int nsl = (workspace == nullptr && slices_env > 0 && slices_env <= 1024) ? slices_env : SK_SLICES;
+    const int nsl = (slices_env > 0 && slices_env <= 1024) ? slices_env : SK_SLICES;
     const long long chunk = (long long)nsl * SK_MAXROWS;          // rows handled per launch
+    const int RRw = R <= 4 ? 4 : 16;
+    if (workspace != nullptr && hipMemsetAsync(workspace, 0, (size_t)SK_COPIES * P * RRw * 4, st) != hipSuccess) return VT_ERR_LAUNCH;
     for (long long mbase = 0; mbase < M; mbase += chunk) {
         const long long mc = (M - mbase) < chunk ? (M - mbase) : chunk;
         const int rps = (int)((mc + nsl - 1) / nsl);
@@ -161,11 +183,13 @@ extern "C" int vt_skinny_tn(const void* Big, int ldb, const void* Small, int lds
         const bf16_t* smp = (const bf16_t*)Small + (size_t)mbase * lds_;
         if (R <= 4) {
             hipLaunchKernelGGL(skinny_tn_kernel<4>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps, workspace);
-            if (workspace) hipLaunchKernelGGL(skinny_reduce_kernel<4>, dim3((P * 4 + 255) / 256), dim3(256), 0, st, workspace, SK_SLICES, out, osp, osr, alpha, P, R);
         } else {
             hipLaunchKernelGGL(skinny_tn_kernel<16>, grid, dim3(128), 0, st, bg, ldb, smp, lds_, R, out, osp, osr, alpha, mc, P, rps, workspace);
-            if (workspace) hipLaunchKernelGGL(skinny_reduce_kernel<16>, dim3((P * 16 + 255) / 256), dim3(256), 0, st, workspace, SK_SLICES, out, osp, osr, alpha, P, R);
         }
+    }
+    if (workspace != nullptr) {
+        if (R <= 4) hipLaunchKernelGGL(skinny_reduce_kernel<4>, dim3((P * 4 + 255) / 256), dim3(256), 0, st, workspace, SK_COPIES, out, osp, osr, alpha, P, R);
+        else hipLaunchKernelGGL(skinny_reduce_kernel<16>, dim3((P * 16 + 255) / 256), dim3(256), 0, st, workspace, SK_COPIES, out, osp, osr, alpha, P, R);
     }
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

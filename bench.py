@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--accum", type=int, default=2)
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["2b", "5b"], default="2b",
+                    help="2b = the benchmark (BASELINE configs[1]); 5b = CogVideoX-5B dimensions (48 heads, 42 layers, rotary q/k) -- "
+                         "extra data point, labelled as such, never the headline line")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
     args = ap.parse_args()
@@ -77,8 +80,16 @@ def main():
     dev = torch.device("cuda", local)
 
     # ---- model: CogVideoX-2B architecture, seeded random init, identical on every rank ----
-    model = CogVideoXTransformer3DModel(num_layers=args.layers)
+    if args.model == "5b":
+        model = CogVideoXTransformer3DModel(num_layers=42 if args.layers == 30 else args.layers, num_attention_heads=48,
+                                            use_rotary_positional_embeddings=True)
+    else:
+        model = CogVideoXTransformer3DModel(num_layers=args.layers)
     model.to(dev)
+    rope = None
+    if args.model == "5b":
+        from vt355.rope import prepare_rotary_positional_embeddings
+        rope = prepare_rotary_positional_embeddings(480, 720, 13, device=dev)        # cogvideo_pl.py:846-859
     gen = torch.Generator(device=dev).manual_seed(1234)
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -119,7 +130,7 @@ def main():
         for mb in range(args.accum):
             x0, text, noise, t = batches[mb]
             noisy = sched.add_noise(x0, noise, t)
-            out = peft(hidden_states=noisy, encoder_hidden_states=text, timestep=t, return_dict=False)[0]
+            out = peft(hidden_states=noisy, encoder_hidden_states=text, timestep=t, image_rotary_emb=rope, return_dict=False)[0]
             sa, sb, w = sched.coefficients(t)
             loss = _LossFn.apply(out, noisy, x0, sa, sb, w)
             if args.mode == "fullft":             # DDP no_sync: slices are all-reduced only on the last micro-batch,
@@ -178,12 +189,13 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")) as f:
                 tr = json.load(f)["traffic"]
             key = [k for k in tr if "attn_bwd_hd64_kernel" in k][0]
-            if args.micro_batch == 2 and args.layers == 30:
+            if args.micro_batch == 2 and args.layers == 30 and args.model == "2b":
                 traffic = tr[key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         res = {
-            "metric": "finetune samples/sec, CogVideoX-2B T2V %s 49x480x720 bf16" % ("LoRA" if args.mode == "lora" else "full-FT"),
+            "metric": "finetune samples/sec, CogVideoX-%s T2V %s 49x480x720 bf16" % ("2B" if args.model == "2b" else "5B",
+                                                                                       "LoRA" if args.mode == "lora" else "full-FT"),
             "value": samples / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -192,9 +204,10 @@ def main():
                                     "text [2,226,4096], r=4 LoRA on to_q/k/v/out, accumulate_grad_batches 2") if args.mode == "lora" else
                                    ("CogVideoX-2B T2V FULL finetune 49x480x720 (configs[2]): all 1.69 B weights trainable, fp32 master "
                                     "+ fused AdamW, per-block gradient slices all-reduced under the backward"),
-                       "mode": args.mode,
+                       "mode": args.mode, "model": "CogVideoX-" + args.model.upper() + ("" if args.model == "2b" else
+                                                                                          " (NOT the benchmark config: extra data point)"),
                        "micro_batch": args.micro_batch, "accumulate_grad_batches": args.accum,
-                       "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": args.layers,
+                       "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": model.config.num_layers,
                        "parallelism": f"dp{world}", "recompute": "none (activations kept in HBM)",
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,

@@ -409,3 +409,26 @@ def test_group_colsum(dev):
         for seg, rows in ((0, slice(b * S, b * S + St)), (1, slice(b * S + St, (b + 1) * S))):
             close(o1[2 * b + seg], x[rows].sum(0), 1e-4, 2e-3, "group sum")
             close(o2[2 * b + seg], (x[rows] * yn[rows]).sum(0), 1e-4, 3e-3, "group sum of products")
+
+
+# ------------------------------------------------------------------ error behaviour of the C-ABI
+def test_abi_rejects_bad_arguments(dev):
+    """The library validates shapes / alignment on the host and returns a negative code (no launch, no fault): the Python
+    binding turns it into VtError.  Mirrors how the reference's own layers fail loudly on shape mismatches."""
+    from vt355 import ops
+    from vt355._lib import VtError
+    a = torch.zeros(64, 128, dtype=BF, device=dev); w = torch.zeros(64, 128, dtype=BF, device=dev)
+    out = torch.zeros(64, 64, dtype=BF, device=dev)
+    with pytest.raises(VtError, match="vt_gemm_bf16"):              # K not a multiple of the 64-deep K-tile
+        ops.gemm(a, w, out, None, K=100)
+    with pytest.raises(VtError):                                     # misaligned operand (16-byte rule of the LDS-DMA path)
+        ops.gemm(a.view(-1)[4:4 + 63 * 128].view(63, 128), w, out[:63], None)
+    with pytest.raises(VtError, match="vt_gemm_nt_bf16"):           # dW tile sizes must be multiples of 128
+        ops.gemm_nt(a, w, torch.zeros(100, 128, device=dev), P=100, Q=128)
+    with pytest.raises(VtError, match="vt_gemm_set_tile"):
+        ops.gemm_set_tile(7)
+    with pytest.raises(VtError, match="vt_attn_bwd_set_chain"):      # persistent grid must be a multiple of 8 slots
+        ops.attn_bwd_set_chain(0, 12)
+    ops.attn_bwd_set_chain(0, 0)
+    with pytest.raises((VtError, TypeError, ValueError)):            # host tensors are refused: there is no CPU path
+        ops.gemm(a.cpu(), w.cpu(), out.cpu(), None)

@@ -15,6 +15,10 @@
 // fused QKV GEMM output [B*S, 3*H*64] is consumed in place (no head transpose copies).
 #include "common.h"
 
+#ifndef VT_FWD_DMA
+#define VT_FWD_DMA 1     // 1 = K / V tiles staged by LDS-DMA (buffer_load ... lds), 0 = global -> VGPR -> ds_write_b128
+#endif
+
 struct AttnFwdParams {
     const bf16_t* q;
     const bf16_t* k;
@@ -71,6 +75,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         k_lds[j] = key * 128 + ((c ^ ((key >> 1) & 7)) << 4);
         v_lds[j] = 8192 + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4);
     }
+#if VT_FWD_DMA
+    // LDS-DMA staging: a K (or V) tile of 64 keys is 8 pieces of 1 KiB = 8 rows x 128 B; wave w moves pieces w and w+4 of each.
+    // Lane l lands at (row l>>3, physical chunk l&7) of its piece and fetches the logical chunk the image's swizzle puts there.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int kd_voff[2], vd_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 8 * (wv + 4 * j) + (lane >> 3);
+        kd_voff[j] = (int)(key * p.k_rs * 2) + (((lane & 7) ^ ((key >> 1) & 7)) << 4);
+        vd_voff[j] = (int)(key * p.v_rs * 2) + (((lane & 7) ^ (((key >> 1) & 1) << 2)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+        const int ks = (int)((long long)t * FK * p.k_rs * 2);
+        const int vs = (int)((long long)t * FK * p.v_rs * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* dst = smem + buf * 16384 + (wv + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kd_voff[j], ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + 8192), 16, vd_voff[j], vs, 0, 0);
+        }
+    };
+#endif
     u32x4 gk[2], gv[2];
     auto gload = [&](int t) {
         const int ks = (int)((long long)t * FK * p.k_rs * 2);
@@ -118,12 +144,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
     const float sc = p.scale_log2;
 
     const int nt = (p.S + FK - 1) / FK;
+#if VT_FWD_DMA
+    dma(0, 0);
+#else
     gload(0);
     lstore(0);
+#endif
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
+#if VT_FWD_DMA
+        if (t + 1 < nt) dma(t + 1, buf ^ 1);
+#else
         if (t + 1 < nt) gload(t + 1);
+#endif
         const char* base = smem + buf * 16384;
 
         f32x16 st[2];
@@ -242,8 +276,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
                 }
             }
         }
+#if !VT_FWD_DMA
         if (t + 1 < nt) lstore(buf ^ 1);
-        __syncthreads();
+#endif
+        __syncthreads();       // (DMA build: its vmcnt(0) also retires the next tile's LDS-DMA)
     }
 
     // ---- finalize: O = O^T / l, LSE ----

@@ -31,13 +31,18 @@ struct AttnFwdParams {
     float scale_log2;
 };
 
-#define FQ 128      // queries per workgroup
+#ifndef VT_FWD_WAVES
+#define VT_FWD_WAVES 4  // waves per workgroup (32 queries each).  8 (256 queries share every K / V tile, half the staging per flop) measured
+                        // within 1 % of 4 (2.447 vs 2.425 ms at B=1): staging is no longer what limits this kernel
+#endif
+#define FQ (32 * VT_FWD_WAVES)      // queries per workgroup
+#define FWD_THREADS (64 * VT_FWD_WAVES)
 #define FK 64       // keys per tile
 #define NEG_BIG (-1.0e30f)
 #define LAZY_THR 8.0f
 
 template <bool PRESCALED>
-__global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) {
+__global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn_fwd_hd64_kernel(AttnFwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[32768];   // 2 x (K 8 KiB + V 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -65,10 +70,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
     }
 
     // ---- staging assignment: 2 x 16-byte chunks of K and of V per thread per tile ----
+    constexpr int NCH = 512 / FWD_THREADS;       // 16-byte chunks of K (and of V) per thread per tile
     int k_voff[2], v_voff[2], k_lds[2], v_lds[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int i = tid + 256 * j;
+    for (int j = 0; j < NCH; ++j) {
+        int i = tid + FWD_THREADS * j;
         int key = i >> 3, c = i & 7;
         k_voff[j] = (int)(key * p.k_rs * 2) + c * 16;
         v_voff[j] = (int)(key * p.v_rs * 2) + c * 16;
@@ -79,10 +85,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
     // LDS-DMA staging: a K (or V) tile of 64 keys is 8 pieces of 1 KiB = 8 rows x 128 B; wave w moves pieces w and w+4 of each.
     // Lane l lands at (row l>>3, physical chunk l&7) of its piece and fetches the logical chunk the image's swizzle puts there.
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int NPC = 8 / VT_FWD_WAVES;        // 1-KiB pieces of K (and of V) per wave per tile
     int kd_voff[2], vd_voff[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int key = 8 * (wv + 4 * j) + (lane >> 3);
+    for (int j = 0; j < NPC; ++j) {
+        const int key = 8 * (wv + VT_FWD_WAVES * j) + (lane >> 3);
         kd_voff[j] = (int)(key * p.k_rs * 2) + (((lane & 7) ^ ((key >> 1) & 7)) << 4);
         vd_voff[j] = (int)(key * p.v_rs * 2) + (((lane & 7) ^ (((key >> 1) & 1) << 2)) << 4);
     }
@@ -90,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         const int ks = (int)((long long)t * FK * p.k_rs * 2);
         const int vs = (int)((long long)t * FK * p.v_rs * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            char* dst = smem + buf * 16384 + (wv + 4 * j) * 1024;
+        for (int j = 0; j < NPC; ++j) {
+            char* dst = smem + buf * 16384 + (wv + VT_FWD_WAVES * j) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kd_voff[j], ks, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + 8192), 16, vd_voff[j], vs, 0, 0);
         }
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
         const int ks = (int)((long long)t * FK * p.k_rs * 2);
         const int vs = (int)((long long)t * FK * p.v_rs * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             gk[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, k_voff[j], ks, 0));
             gv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, v_voff[j], vs, 0));
         }
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_hd64_kernel(AttnFwdParams p) 
     auto lstore = [&](int buf) {
         char* base = smem + buf * 16384;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             *(u32x4*)(base + k_lds[j]) = gk[j];
             *(u32x4*)(base + v_lds[j]) = gv[j];
         }
@@ -319,7 +326,7 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const int nqt = (S + FQ - 1) / FQ;
-    if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
+    if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

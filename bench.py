@@ -213,8 +213,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_summary.json; "
-                                         "~9.5 GB of it are fp32 dQ atomics -- one set per PAIR of key blocks -- and ~2.5 GB hand-off tiles evicted "
-                                         "from the L2; algorithmic bytes are 1.1 GB)",
+                                         "~9.5 GB of it are fp32 dQ atomics -- one set per PAIR of key blocks -- most of the rest hand-off tiles "
+                                         "evicted from the L2; algorithmic bytes are 1.1 GB)",
                          "note": "algorithmic FLOPs per launch 8*S^2*d*B (dQ,dK,dV products; P recompute not counted)"},
             "kernels": kern,
             "loss_last": loss_vals[-1], "loss_first": loss_vals[0],

@@ -379,7 +379,7 @@ def test_lora_kernels(dev):
 
 
 # ------------------------------------------------------------------ weight-gradient GEMM and column reductions (full fine-tune)
-@pytest.mark.parametrize("M,P,Q", [(200, 128, 128), (1000, 256, 384), (17776, 1920, 1920), (129, 384, 128)])
+@pytest.mark.parametrize("M,P,Q", [(200, 128, 128), (1000, 256, 384), (17776, 1920, 1920), (129, 384, 128), (4500, 1152, 1024), (9001, 640, 1920)])
 def test_gemm_nt(dev, M, P, Q):
     from vt355 import ops
     g = torch.Generator().manual_seed(M + P)

@@ -133,6 +133,132 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Producer / consumer version (see gemm_pc_bf16.hip for the idea): 256 (P) x 128 (Q) output tile, waves 0..3 only
+// multiply (128 x 64 each = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16, both fragments from transposed reads), waves 4..7
+// only issue LDS-DMA, two 64-token K-tiles ahead in a three-stage ring of 48 KiB stages:
+//   stage = A columns [0,128) image | A columns [128,256) image | B image, each [64 tokens][256 B] with the nt_swz swizzle.
+// P need only be a multiple of 128: the columns of a ragged last tile beyond P are computed from whatever follows in the
+// rows of A (in bounds; the matrix end reads zeros) and never stored.
+// ------------------------------------------------------------------------------------------------
+#define NTP_STAGE 49152
+static __device__ __forceinline__ void ntp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_pc_kernel(GemmNtParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * NTP_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbp = (p.P + 255) / 256, nbq = p.Q / 128;
+    const int id = xcd_remap(blockIdx.x, nbp * nbq);
+    const int tile_p = id % nbp, tile_q = id / nbp;
+    const int p0 = tile_p * 256, q0 = tile_q * 128;
+    const int m_lo = (int)blockIdx.y * p.m_chunk;
+    const int m_cnt = min(p.M - m_lo, p.m_chunk);
+    const int nk = (m_cnt + 63) / 64;
+
+    if (wave >= 4) {
+        // ---------------- loaders: blocks of 1 KiB = 4 token rows x 256 B; wave lw moves blocks lw, lw+4, lw+8, lw+12 of each image ----------------
+        const int lw = wave - 4;
+        const bf16_t* Ab = p.A + (size_t)m_lo * p.lda;
+        const bf16_t* Bb = p.B + (size_t)m_lo * p.ldb;
+        const long long a_bytes = (long long)m_cnt * p.lda * 2, b_bytes = (long long)m_cnt * p.ldb * 2;
+        __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab + p0, (unsigned)((a_bytes - p0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (a_bytes - p0 * 2)));
+        __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb + q0, (unsigned)((b_bytes - q0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (b_bytes - q0 * 2)));
+        // lane l lands at (row l>>4, physical chunk l&15) of its block and fetches logical chunk (l&15) ^ nt_swz(row);
+        // nt_swz(4 (lw + 4 j) + drl) does not depend on j, so the block step (16 rows) is a scalar offset
+        const int drl = lane >> 4, dcp = lane & 15;
+        const int row0 = 4 * lw + drl;
+        const int ch = dcp ^ nt_swz(row0);
+        const int a_voff = row0 * p.lda * 2 + ch * 16, b_voff = row0 * p.ldb * 2 + ch * 16;
+        const int a_step = 16 * p.lda * 2, b_step = 16 * p.ldb * 2;
+        auto issue = [&](int kt) {
+            const int sa = kt * 64 * p.lda * 2, sb = kt * 64 * p.ldb * 2;
+            char* st = smem + (kt % 3) * NTP_STAGE + lw * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + j * 4096), 16, a_voff, sa + j * a_step, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + 16384 + j * 4096), 16, a_voff, sa + j * a_step + 256, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(st + 32768 + j * 4096), 16, b_voff, sb + j * b_step, 0, 0);
+            }
+        };
+        int issued = 0;
+        for (; issued < 2 && issued < nk; ++issued) issue(issued);
+        for (int g = 0; g < nk; ++g) {
+            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // K-tile g landed, g+1 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ntp_barrier();                   // stage g % 3 ready / stage (g-1) % 3 consumed
+            if (issued < nk) { issue(issued); ++issued; }
+        }
+        return;
+    }
+
+    // ---------------- multipliers ----------------
+    const int wp = wave & 1, wq = wave >> 1;
+    const int g4 = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
+    // transposed-read offsets: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of its block
+    auto tr_addr = [&](const char* img, int slab_col0, int ks, int sec, int t) {
+        const int row = ks * 32 + 8 * g4 + ql + 4 * sec;
+        const int col = slab_col0 + t * 16 + 4 * pl;
+        return img + row * 256 + (((col >> 3) ^ nt_swz(row)) << 4) + (col & 7) * 2;
+    };
+    f32x4 acc[8][4];     // [tp][tq]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Software pipeline over the flattened (K-tile, k-step) sequence: during the MFMAs of one step the fragments of the next
+    // are fetched - the A fragment of row tile tp into the registers its last MFMA has just released, the B fragments into
+    // the other half of bfr. Step (g, 1) fetches from stage g + 1, so barrier g + 1 sits at its start; by then every read
+    // of stage g has been issued, and ntp_barrier() waits for them before it signals.
+    bf16x8 af[8], bfr[2][4];
+    ntp_barrier();                           // barrier 0: the loaders have landed stage 0
+    {
+        const char* As = smem + wp * 16384;
+        const char* Bs = smem + 32768;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) af[t] = nt_tr_pair(tr_addr(As, 0, 0, 0, t), tr_addr(As, 0, 0, 1, t));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bfr[0][t] = nt_tr_pair(tr_addr(Bs, wq * 64, 0, 0, t), tr_addr(Bs, wq * 64, 0, 1, t));
+    }
+    for (int g = 0; g < nk; ++g) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // source of the next step's fragments (after the last K-tile: a harmless read of a stale stage, never used)
+            const int ng = ks == 0 ? g : g + 1, nks = ks ^ 1;
+            if (ks == 1 && g + 1 < nk) ntp_barrier();
+            const char* As = smem + (ng % 3) * NTP_STAGE + wp * 16384;
+            const char* Bs = smem + (ng % 3) * NTP_STAGE + 32768;
+#pragma unroll
+            for (int tp = 0; tp < 8; ++tp) {
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq)
+                    acc[tp][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tp], bfr[ks][tq], acc[tp][tq], 0, 0, 0);
+                af[tp] = nt_tr_pair(tr_addr(As, 0, nks, 0, tp), tr_addr(As, 0, nks, 1, tp));
+                if (tp < 4) bfr[ks ^ 1][tp] = nt_tr_pair(tr_addr(Bs, wq * 64, nks, 0, tp), tr_addr(Bs, wq * 64, nks, 1, tp));
+                __builtin_amdgcn_sched_barrier(0);       // keep each reload right behind the MFMAs that freed its registers
+            }
+        }
+    }
+    // epilogue: D[i = 4g + reg][j = lane & 15]; each register row is 16 consecutive fp32 columns (64 B) of C
+    const int fr = lane & 15;
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int pr = p0 + wp * 128 + tp * 16 + 4 * g4 + rg;
+                const int qc = q0 + wq * 64 + tq * 16 + fr;
+                if (pr < p.P) {
+                    float* c = p.C + (size_t)pr * p.ldc + qc;
+                    const float v = p.alpha * acc[tp][tq][rg];
+                    if (p.splits > 1) atomicAdd(c, v);
+                    else *c = p.accumulate ? (*c + v) : v;
+                }
+            }
+}
+
+
 extern "C" int vt_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int P, int Q,
                                float alpha, int accumulate, void* stream) {
     if (M <= 0 || P <= 0 || Q <= 0 || (P % 128) || (Q % 128) || (lda % 8) || (ldb % 8) || lda < P || ldb < Q || ldc < Q)
@@ -140,14 +266,18 @@ extern "C" int vt_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, f
     if ((long long)M * lda * 2 >= 0x7fffffffLL || (long long)M * ldb * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return VT_ERR_BAD_ALIGN;
     GemmNtParams p{(const bf16_t*)A, (const bf16_t*)B, C, M, P, Q, lda, ldb, ldc, accumulate, alpha, 1, M};
-    // split the token axis so that the grid fills whole rounds of the chip (2 workgroups per CU); ranges stay >= 2048 tokens
-    const int tiles = (P / 128) * (Q / 128);
-    static int wg_slots = 0;
-    if (wg_slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-        wg_slots = cus > 0 ? 2 * cus : 512;
+    // kernel: the producer / consumer one (256 x 128 tiles, one workgroup per CU) for weight-sized outputs; VT_NT_KERNEL=1|2 forces
+    static int kmode = -1, cus = 0;
+    if (kmode < 0) {
+        const char* e = getenv("VT_NT_KERNEL");
+        kmode = e ? atoi(e) : 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
+    const bool pc = kmode == 2 || (kmode == 0 && (long long)P * Q >= 1024LL * 1024LL && M >= 4096);
+    // split the token axis so that the grid fills whole rounds of the chip; ranges stay >= 2048 tokens
+    const int tiles = pc ? ((P + 255) / 256) * (Q / 128) : (P / 128) * (Q / 128);
+    const int wg_slots = pc ? cus : 2 * cus;
     int best = 1;
     double best_eff = 0.0;
     for (int sp = 1; sp <= 8; ++sp) {
@@ -164,6 +294,7 @@ extern "C" int vt_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, f
         // partial tiles are ADDED: start from zeros
         if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)Q * 4, (size_t)P, st) != hipSuccess) return VT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((P / 128) * (Q / 128), best), dim3(256), 0, st, p);
+    if (pc) hipLaunchKernelGGL(gemm_nt_pc_kernel, dim3(tiles, best), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles, best), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -8,15 +8,13 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics"
 mkdir -p "$HERE/obj_exp"; rm -f "$HERE"/obj_exp/*.o
 # attention backward A/B variants (see csrc/exp/README.md for what was measured with them)
 hipcc $F -DVT_SUFFIX=_nolink -DVT_CHAIN=0 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink.o" &
-hipcc $F -DVT_SUFFIX=_stat -DVT_STATMFMA=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_stat.o" &
-hipcc $F -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8.o" &
 hipcc $F -DVT_W8=0 -DVT_SUFFIX=_w4 -mllvm -amdgpu-sched-strategy=max-ilp -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_w4.o" &
-hipcc $F -DCH_R=8 -DCH_HYST=2 -DVT_SUFFIX=_r8h2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_r8h2.o" &
 hipcc $F -DVT_DQ16=1 -DVT_SUFFIX=_dq16 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_dq16.o" &
 hipcc $F -DVT_SUFFIX=_same -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_same.o" &
-hipcc $F -DW8_NOATOMICS=1 -DVT_SUFFIX=_w8na -c "$HERE/exp/attn_bwd_w8.hip" -o "$HERE/obj_exp/bwd_w8na.o" &
-hipcc $F -DVT_SUFFIX=_nolink_abl2 -DVT_CHAIN=0 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_nolink_abl2.o" &
-hipcc $F -DVT_SUFFIX=_abl2 -DVT_ABL=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl2.o" &
+# timing-only ablations of the eight-wave body (wrong results): which resource the step is bound by
+for a in 1 2 5 6 7; do
+  hipcc $F -DVT_SUFFIX=_abl$a -DVT_ABL=$a -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl$a.o" &
+done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj_exp/*.o
 echo "built $OUT"

@@ -67,6 +67,28 @@ def main():
                 pre = torch.empty(M, N, dtype=BF, device=dev)
                 med, mn = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))
                 print(f"   +gelu epilogue: {med:.3f} ms {2.0*M*N*K/med/1e9:.0f} TF/s", flush=True)
+    if "blas" in which:       # calibration only: the vendor libraries on the same shapes (hipBLASLt through torch.matmul, torch SDPA)
+        import torch.nn.functional as F
+        for (M, N, K, name) in [(2 * S, 5760, 1984, "qkv2"), (2 * S, 7680, 1920, "ff1_2"), (2 * S, 1920, 7680, "ff2_2"), (S, 5760, 1984, "qkv"), (8192, 8192, 8192, "sq8k")]:
+            a = torch.randn(M, K, device=dev).to(BF); w = (torch.randn(N, K, device=dev) * 0.02).to(BF)
+            med, mn = timeit(lambda: torch.matmul(a, w.t()))
+            print(f"torch.matmul {name:5s} M={M} N={N} K={K}: {med:.3f} ms  {2.0*M*N*K/med/1e9:.0f} TF/s (min {mn:.3f})", flush=True)
+        for (M, P, Q, name) in [(S, 5760, 1920, "dW_qkv"), (S, 7680, 1920, "dW_ff1")]:
+            a = torch.randn(M, P, device=dev).to(BF); b = torch.randn(M, Q, device=dev).to(BF)
+            med, mn = timeit(lambda: torch.matmul(a.t(), b))
+            print(f"torch.matmul {name} (bf16 out) M={M} P={P} Q={Q}: {med:.3f} ms  {2.0*M*P*Q/med/1e9:.0f} TF/s", flush=True)
+        try:
+            q = torch.randn(1, 30, S, 64, device=dev).to(BF).requires_grad_(True)
+            k = torch.randn(1, 30, S, 64, device=dev).to(BF).requires_grad_(True)
+            v = torch.randn(1, 30, S, 64, device=dev).to(BF).requires_grad_(True)
+            fl = 4.0 * S * S * 1920
+            med, mn = timeit(lambda: F.scaled_dot_product_attention(q, k, v))
+            print(f"torch SDPA fwd B=1: {med:.3f} ms  {fl/med/1e9:.0f} TF/s", flush=True)
+            o = F.scaled_dot_product_attention(q, k, v); go = torch.randn_like(o)
+            med, mn = timeit(lambda: torch.autograd.grad(o, (q, k, v), go, retain_graph=True))
+            print(f"torch SDPA bwd B=1: {med:.3f} ms  {2*fl/med/1e9:.0f} TF/s algorithmic", flush=True)
+        except Exception as e:      # no flash backend in this torch build
+            print("torch SDPA unavailable:", repr(e)[:200], flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

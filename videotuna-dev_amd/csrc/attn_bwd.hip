@@ -80,7 +80,7 @@
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
 #ifndef VT_ABL
-#define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write
+#define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write, 5 = no row-constant reads, 6 = no transposed Q / dO reads, 7 = 5 + 6 (5..7: eight-wave body)
 #endif
 #define VT_CAT_(a, b) a##b
 #define VT_CAT(a, b) VT_CAT_(a, b)
@@ -351,8 +351,12 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             f32x16 sacc, pacc;
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
+#if VT_ABL == 5 || VT_ABL == 7
+                const f32x4 a = {-8.f, -8.f, -8.f, -8.f}, c = {-0.01f, -0.01f, -0.01f, -0.01f};
+#else
                 const f32x4 a = *(const f32x4*)(lsel + 32 * qs + 8 * gg + 4 * h);
                 const f32x4 c = *(const f32x4*)(lsel + 64 + 32 * qs + 8 * gg + 4 * h);
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { sacc[4 * gg + e] = RAGGED ? a[e] + kmask : a[e]; pacc[4 * gg + e] = c[e]; }
             }
@@ -380,8 +384,13 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 const int ro = (32 * qs + 16 * s2) * 128;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
+#if VT_ABL == 6 || VT_ABL == 7
+                    (void)ro;
+                    const bf16x8 doT = vf[2 * s2 + dt], qT = kf[2 * s2 + dt];
+#else
                     const bf16x8 doT = tr_pair(doimg + ro + trA[dt][0], doimg + ro + trA[dt][1]);
                     const bf16x8 qT = tr_pair(qimg + ro + trA[dt][0], qimg + ro + trA[dt][1]);
+#endif
                     dv_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pb, dv_acc[dt], 0, 0, 0);
                     dk_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, dsb, dk_acc[dt], 0, 0, 0);
                 }

@@ -89,6 +89,29 @@ def main():
             print(f"torch SDPA bwd B=1: {med:.3f} ms  {2*fl/med/1e9:.0f} TF/s algorithmic", flush=True)
         except Exception as e:      # no flash backend in this torch build
             print("torch SDPA unavailable:", repr(e)[:200], flush=True)
+    if "epi" in which:        # the two FF GEMMs with their fused GELU / dGELU epilogues at the bench micro-batch (B=2)
+        M = 2 * S
+        a = torch.randn(M, 1920, device=dev).to(BF); w = (torch.randn(7680, 1920, device=dev) * 0.02).to(BF)
+        out = torch.empty(M, 7680, dtype=BF, device=dev); pre = torch.empty(M, 7680, dtype=BF, device=dev); b = torch.zeros(7680, dtype=BF, device=dev)
+        g = torch.randn(M, 1920, device=dev).to(BF); w2 = (torch.randn(1920, 7680, device=dev) * 0.02).to(BF); w2t = w2.t().contiguous()
+        fl = 2.0 * M * 7680 * 1920
+        for mode, tag in ((1, "tile128"), (2, "tile256"), (3, "tile_pc "), (0, "auto    ")):
+            ops.gemm_set_tile(mode)
+            m0, _ = timeit(lambda: ops.gemm(a, w, out, b))
+            m1, _ = timeit(lambda: ops.gemm(a, w, out, b, epilogue=ops.EPI_BIAS_GELU, pre_act_out=pre))
+            m2, _ = timeit(lambda: ops.gemm(g, w2t, out, None, epilogue=ops.EPI_DGELU, pre_act_in=pre))
+            print(f"ff1 {tag}: plain {m0:.3f} ms {fl/m0/1e9:.0f} TF/s | +GELU {m1:.3f} ms {fl/m1/1e9:.0f} | dX*dGELU {m2:.3f} ms {fl/m2/1e9:.0f}", flush=True)
+        ops.gemm_set_tile(0)
+        # attention / FF output projections with the gated residual epilogue (K = 1920 + 64 LoRA columns, and the FF one)
+        res_ = torch.randn(M, 1920, device=dev).to(BF); gt = torch.randn(2, 1920, device=dev); gv = torch.randn(2, 1920, device=dev)
+        o2 = torch.empty(M, 1920, dtype=BF, device=dev); b2 = torch.zeros(1920, dtype=BF, device=dev)
+        for K_ in (1984, 7680):
+            a2 = torch.randn(M, K_, device=dev).to(BF); w3 = (torch.randn(1920, K_, device=dev) * 0.02).to(BF)
+            fl2 = 2.0 * M * 1920 * K_
+            m0, _ = timeit(lambda: ops.gemm(a2, w3, o2, b2))
+            m1, _ = timeit(lambda: ops.gemm(a2, w3, o2, b2, epilogue=ops.EPI_GATED_RES, residual=res_, gate_txt=gt, gate_vid=gv,
+                                            gate_bstride=1920, S=S, St=226))
+            print(f"proj K={K_}: plain {m0:.3f} ms {fl2/m0/1e9:.0f} TF/s | +gated residual {m1:.3f} ms {fl2/m1/1e9:.0f}", flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

@@ -61,22 +61,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+// tanh-GELU as x * sigmoid(2u), u = k0 (x + k1 x^3): sigmoid(2u) = 1 - 1 / (2^(2 log2e u) + 1) with the hardware exp2 / rcp
+// (no IEEE division: these run in GEMM epilogues while the matrix pipe waits).  Saturates correctly: 2^w = inf -> s = 1,
+// 2^w = 0 -> s = 0.
+__device__ __forceinline__ float gelu_sigmoid_f(float x, float x2) {
+    const float c0 = 2.0f * 1.4426950408889634f * 0.7978845608028654f, c1 = c0 * 0.044715f;
+    const float w = x * __builtin_fmaf(c1, x2, c0);
+    return 1.0f - __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(w) + 1.0f);
 }
+__device__ __forceinline__ float gelu_tanh_f(float x) { return x * gelu_sigmoid_f(x, x * x); }
+// d/dx [x s(x)] = s + x s (1 - s) * 2 du/dx,  du/dx = k0 (1 + 3 k1 x^2)
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float x2 = x * x;
-    float u = k0 * (x + k1 * x * x2);
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    float du = k0 * (1.0f + 3.0f * k1 * x2);
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+    const float x2 = x * x;
+    const float sg = gelu_sigmoid_f(x, x2);
+    const float du2 = __builtin_fmaf(6.0f * k0 * k1, x2, 2.0f * k0);
+    return __builtin_fmaf(x * du2, sg * (1.0f - sg), sg);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -220,6 +220,18 @@ __global__ __launch_bounds__(GB_THREADS, 1) void GEMM_BIG_KERNEL(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
         }
+        // second operand of the epilogue (residual / saved pre-activation): fetched one slab ahead of its use
+        constexpr bool HAS_AUX = EPI == EPI_GATED_RES || EPI == EPI_DGELU;
+        u32x2 aux[4], auxn[4];
+        auto aux_fetch = [&](int slab, u32x2* dst) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = cur.row0 + slab * 32 + pass * 8 + er;
+                dst[pass] = (u32x2){0u, 0u};
+                if (HAS_AUX && wave < 8 && m < p.M && n < p.N) dst[pass] = gemm_epilogue_aux_load<EPI>(p, m, n);
+            }
+        };
+        aux_fetch(0, aux);
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
             if (wave < 8 && wm == (slab >> 2)) {
@@ -234,16 +246,19 @@ __global__ __launch_bounds__(GB_THREADS, 1) void GEMM_BIG_KERNEL(GemmParams p) {
                     }
             }
             gb_lds_barrier();
+            if (slab < 7) aux_fetch(slab + 1, auxn);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int ml = pass * 8 + er;
                 const int m = cur.row0 + slab * 32 + ml;
                 if (wave < 8 && m < p.M && n < p.N) {
                     const f32x4 v = *(const f32x4*)(Cs + ml * GB_CS_LD + ec);
-                    gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
+                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass]);
                 }
             }
             gb_lds_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) aux[pass] = auxn[pass];
         }
         cur = nxt;
     }

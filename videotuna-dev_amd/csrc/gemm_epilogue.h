@@ -22,10 +22,23 @@ struct GemmParams {
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_DGELU = 3 };
 
 
+// The epilogues that read a second operand (EPI_GATED_RES: residual R, EPI_DGELU: saved pre-activation U) take its four
+// bf16 values of (row m, columns n..n+3) as `aux`, so that a kernel can fetch them a slab ahead of their use.
+template <int EPI>
+__device__ __forceinline__ u32x2 gemm_epilogue_aux_load(const GemmParams& p, int m, int n) {
+    if (EPI == EPI_GATED_RES) {
+        const int rr = p.r_mod > 0 ? (m % p.r_mod) : m;
+        return *(const u32x2*)(p.R + (size_t)rr * p.ldr + n);
+    } else if (EPI == EPI_DGELU) {
+        return *(const u32x2*)(p.U + (size_t)m * p.ldu + n);
+    }
+    return (u32x2){0u, 0u};
+}
+
 // v = accumulators of (row m, columns n..n+3), bias4 = bias of those columns (zeros if none).  Caller guarantees
 // m < M and n < N (N % 4 == 0).
 template <int EPI, bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, int n, f32x4 v, const float* bias4) {
+__device__ __forceinline__ void gemm_epilogue_store_aux(const GemmParams& p, int m, int n, f32x4 v, const float* bias4, u32x2 aux) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = v[j] + bias4[j];
@@ -43,8 +56,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
                         u2[1] = pack2(o[2], o[3]);
                         *(u32x2*)(p.C2 + (size_t)m * p.ldc2 + n) = u2;
                     }
-                    const int rr = p.r_mod > 0 ? (m % p.r_mod) : m;
-                    u32x2 r2 = *(const u32x2*)(p.R + (size_t)rr * p.ldr + n);
+                    const u32x2 r2 = aux;
                     float r[4] = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
                                   __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
                     if (p.gate_vid != nullptr) {
@@ -59,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
                         for (int j = 0; j < 4; ++j) o[j] = r[j] + o[j];
                     }
                 } else if (EPI == EPI_DGELU) {
-                    u32x2 u2 = *(const u32x2*)(p.U + (size_t)m * p.ldu + n);
+                    const u32x2 u2 = aux;
                     float u[4] = {__uint_as_float(u2[0] << 16), __uint_as_float(u2[0] & 0xffff0000u),
                                   __uint_as_float(u2[1] << 16), __uint_as_float(u2[1] & 0xffff0000u)};
 #pragma unroll
@@ -73,4 +85,9 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, 
                     c2[1] = pack2(o[2], o[3]);
                     *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = c2;
                 }
+}
+
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int m, int n, f32x4 v, const float* bias4) {
+    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, gemm_epilogue_aux_load<EPI>(p, m, n));
 }

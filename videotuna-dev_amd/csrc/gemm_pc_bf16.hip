@@ -178,6 +178,18 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
         }
+        // second operand of the epilogue (residual / saved pre-activation): fetched one slab ahead of its use
+        constexpr bool HAS_AUX = EPI == EPI_GATED_RES || EPI == EPI_DGELU;
+        u32x2 aux[4], auxn[4];
+        auto aux_fetch = [&](int slab, u32x2* dst) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = cur.row0 + slab * 32 + pass * 8 + er;
+                dst[pass] = (u32x2){0u, 0u};
+                if (HAS_AUX && m < p.M && n < p.N) dst[pass] = gemm_epilogue_aux_load<EPI>(p, m, n);
+            }
+        };
+        aux_fetch(0, aux);
         gp_barrier();                        // every multiplier is done reading the stage (the loaders mirror this one too)
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
@@ -193,16 +205,19 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                     }
             }
             gp_barrier();
+            if (slab < 7) aux_fetch(slab + 1, auxn);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int ml = pass * 8 + er;
                 const int m = cur.row0 + slab * 32 + ml;
                 if (m < p.M && n < p.N) {
                     const f32x4 v = *(const f32x4*)(Cs + ml * GP_CS_LD + ec);
-                    gemm_epilogue_store<EPI, OUT_F32>(p, m, n, v, bias4);
+                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass]);
                 }
             }
             gp_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) aux[pass] = auxn[pass];
         }
     }
 }

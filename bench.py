@@ -193,6 +193,11 @@ def main():
                 traffic = tr[key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        from vt355 import engine as _eng
+        _kept = _eng.saved_bytes_per_block(model, args.micro_batch * S) * model.config.num_layers / 1e9
+        recompute_note = ("per block (VT355_RECOMPUTE / enable_gradient_checkpointing: activations rebuilt in the backward pass)"
+                          if _eng._use_recompute(model, (args.micro_batch * S,)) else
+                          "none (%.0f GB of block activations kept in HBM)" % _kept)
         res = {
             "metric": "finetune samples/sec, CogVideoX-%s T2V %s 49x480x720 bf16" % ("2B" if args.model == "2b" else "5B",
                                                                                        "LoRA" if args.mode == "lora" else "full-FT"),
@@ -208,7 +213,7 @@ def main():
                                                                                           " (NOT the benchmark config: extra data point)"),
                        "micro_batch": args.micro_batch, "accumulate_grad_batches": args.accum,
                        "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": model.config.num_layers,
-                       "parallelism": f"dp{world}", "recompute": "none (activations kept in HBM)",
+                       "parallelism": f"dp{world}", "recompute": recompute_note,
                        "weights": "seeded random init (no checkpoints offline)"},
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,

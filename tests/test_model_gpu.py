@@ -193,3 +193,48 @@ def test_encoder_prefetcher_overlaps_on_a_side_stream(dev):
         assert b["i"] == k
         assert torch.equal(b["latents"], want[k])   # consumed on the main stream after the event wait
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["lora", "fullft"])
+def test_block_recompute_gives_the_same_gradients(dev, mode):
+    """enable_gradient_checkpointing("always") (the reference's policy, cogvideo_pl.py:141) rebuilds every
+    block's activations from its input in the backward pass: same loss bit for bit, same gradients up to the order of the
+    fp32 atomic adds."""
+    import cogvideox_oracle as O
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.fullft import enable_full_finetune
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.selfcheck import CFG_KEYS, build_tiny
+    from vt355.workflow import _LossFn
+    if mode == "lora":
+        cfg, model, peft, st = build_tiny(dev)
+        call, grad = peft, st.grad
+    else:
+        cfg = O.tiny_config()
+        model = CogVideoXTransformer3DModel(**{k: getattr(cfg, k) for k in CFG_KEYS}).init_weights(11, std=0.05).to(dev)
+        ft = enable_full_finetune(model)
+        call, grad = model, ft.grad
+    g = torch.Generator().manual_seed(3)
+    Fr = (cfg.sample_frames - 1) // 4 + 1
+    x0 = torch.randn(2, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g).to(dev)
+    text = (torch.randn(2, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    t = torch.tensor([120, 870], device=dev)
+    sched = CogVideoXDPMScheduler()
+    noisy = sched.add_noise(x0, torch.randn(x0.shape, generator=g).to(dev), t)
+    sa, sb, w = sched.coefficients(t)
+
+    def step(policy):
+        model.enable_gradient_checkpointing(policy)
+        grad.zero_()
+        out = call(hidden_states=noisy, encoder_hidden_states=text, timestep=t)[0]
+        loss = _LossFn.apply(out, noisy, x0, sa, sb, w)
+        loss.backward()
+        return loss.item(), grad.clone()
+    l0, g0 = step("never")
+    l1, g1 = step("always")
+    assert l0 == l1
+    assert g0.abs().max().item() > 0
+    rel = (g1 - g0).norm().item() / g0.norm().item()
+    assert rel < 1e-3, rel
+    with pytest.raises(ValueError):
+        model.enable_gradient_checkpointing("sometimes")

@@ -167,6 +167,7 @@ class CogVideoXTransformer3DModel(nn.Module):
         self.norm_out = no
         self.proj_out = Linear(d, c.patch_size ** 2 * c.out_channels)
         self.gradient_checkpointing = False
+        self.recompute = "never"          # set by enable_gradient_checkpointing()
         self._packed = None           # engine operands, built lazily from the parameters
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
         self.lora = None              # set by vt355.lora.inject
@@ -181,10 +182,14 @@ class CogVideoXTransformer3DModel(nn.Module):
     def device(self):
         return self.proj_out.weight.device
 
-    def enable_gradient_checkpointing(self):
-        """API parity with diffusers (cogvideo_pl.py:141).  On a 288 GB MI355X the engine keeps the ~27 GB/sample
-        of block activations instead of recomputing them (-25 % FLOPs); the flag is recorded, not needed."""
+    def enable_gradient_checkpointing(self, mode: str = "auto"):
+        """API parity with diffusers (cogvideo_pl.py:141): per-block activation recompute.  ``mode`` "auto" (default) keeps
+        the ~27 GB/sample of block activations while they fit comfortably in the free HBM of a 288 GB MI355X (-25 % executed
+        FLOPs) and recomputes each block from its input otherwise; "always" / "never" force either (engine._use_recompute)."""
+        if mode not in ("auto", "always", "never"):
+            raise ValueError(f"mode must be auto | always | never, got {mode!r}")
         self.gradient_checkpointing = True
+        self.recompute = mode
 
     def init_weights(self, seed: int = 0, std: float = 0.02):
         """Seeded random init (no checkpoints offline): W,b ~ N(0, std), LayerNorm gamma ~ 1 + N(0, std)."""

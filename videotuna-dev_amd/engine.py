@@ -125,6 +125,91 @@ def _mod(mod: torch.Tensor, idx: int, d: int):
                            bs=mod.stride(0))
 
 
+def saved_bytes_per_block(model, M: int) -> int:
+    """activation bytes one block keeps for its backward pass (bf16 rows of width d unless noted)"""
+    d = model.inner_dim
+    ext = EXT if model.lora is not None else 0
+    cols = 2 * (d + ext) + 3 * d + 2 * d + d + model.config.ff_mult * d + d         # x1, o | qkv | qkh | h1 | u | h_in
+    if getattr(model, "fullft", None) is not None:
+        cols += d + model.config.ff_mult * d + 2 * d                                  # x2 | g | ao, fo
+    return M * cols * 2
+
+
+def _use_recompute(model, dims) -> bool:
+    """Per-block activation recompute (the reference's enable_gradient_checkpointing(), cogvideo_pl.py:141).
+    ``model.recompute``: "never" | "always" | "auto" (default once enable_gradient_checkpointing() was called: recompute only
+    when the kept activations would not fit comfortably in the free HBM -- on a 288 GB MI355X the benchmark configuration
+    keeps them: -25 % executed FLOPs).  VT355_RECOMPUTE overrides."""
+    import os
+    mode = os.environ.get("VT355_RECOMPUTE") or getattr(model, "recompute", "never")
+    if mode == "always":
+        return True
+    if mode != "auto":
+        return False
+    need = saved_bytes_per_block(model, dims[-1]) * model.config.num_layers
+    free, _ = torch.cuda.mem_get_info()
+    return need > 0.6 * free
+
+
+def block_forward(model, i: int, h, mod, dims, rope, save: bool, scratch):
+    """One CogVideoXBlock forward (diffusers CogVideoXBlock via cogvideo_pl.py:865-871): returns (h_out, a) where a holds
+    what the block's backward needs (only ``h_in`` unless ``save``).  Called again from the backward pass when the block's
+    activations are recomputed instead of kept."""
+    c = model.config
+    P = packed(model)
+    st = model.lora
+    ft = getattr(model, "fullft", None)
+    d, H = model.inner_dim, c.num_attention_heads
+    B, Fr, C, Hh, Ww, S, St, Sv, M = dims
+    dev = h.device
+    KE = d + EXT if st is not None else d        # GEMM reduction length on the LoRA-extended operands
+    r3 = 3 * st.r if st is not None else 0
+    E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+    xg, gbuf = scratch.xg, scratch.gbuf
+    Lw = P.layers[i]
+    m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
+    a = SimpleNamespace(h_in=h)
+    # --- attention branch ---
+    x1 = E(M, d + EXT)
+    a.mean1, a.rstd1 = E(M, dt=torch.float32), E(M, dt=torch.float32)
+    ops.ln_modulate_fwd(h, x1, Lw.n1g, Lw.n1b, (m1.shift_txt, m1.scale_txt, m1.shift_vid, m1.scale_vid, m1.bs),
+                        a.mean1, a.rstd1, d, S, St, c.norm_eps)
+    if st is not None:
+        ops.lora_down(x1, st.a_qkv(st.flat_bf16, i), r3, x1[:, d:], d)
+    qkv = E(M, 3 * d)
+    ops.gemm(x1, Lw.w_qkv, qkv, Lw.b_qkv, K=KE)
+    qkh = E(M, 2 * d)
+    a.qmean, a.qrstd = E(M, 2 * H, dt=torch.float32), E(M, 2 * H, dt=torch.float32)
+    ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6, q_scale=Q_PRESCALE, rope=rope)
+    o = E(M, d + EXT)
+    lse = E(B, H, S, dt=torch.float32)
+    qk3, qkv3, o3 = qkh.view(B, S, 2 * d), qkv.view(B, S, 3 * d), o.view(B, S, d + EXT)
+    ops.attn_fwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], o3[:, :, :d], lse, B, H, S, q_prescaled=True)
+    if st is not None:
+        ops.lora_down(o, st.a_out(st.flat_bf16, i), st.r, o[:, d:], d)
+    h1 = E(M, d)
+    ao = E(M, d) if (save and ft is not None) else None           # branch output before gating (gate gradient)
+    ops.gemm(o, Lw.w_o, h1, Lw.b_o, epilogue=EPI_GATED_RES, residual=h, gate_txt=m1.gate_txt, gate_vid=m1.gate_vid,
+             gate_bstride=m1.bs, S=S, St=St, K=KE, pre_act_out=ao)
+    # --- feed-forward branch ---
+    a.mean2, a.rstd2 = E(M, dt=torch.float32), E(M, dt=torch.float32)
+    keep_ff = save and ft is not None                              # dW1 / dW2 need the FF inputs
+    x2 = E(M, d) if keep_ff else xg
+    gact = E(M, c.ff_mult * d) if keep_ff else gbuf
+    ops.ln_modulate_fwd(h1, x2, Lw.n2g, Lw.n2b, (m2.shift_txt, m2.scale_txt, m2.shift_vid, m2.scale_vid, m2.bs),
+                        a.mean2, a.rstd2, d, S, St, c.norm_eps)
+    u = E(M, c.ff_mult * d) if save else gbuf.new_empty(M, c.ff_mult * d)
+    ops.gemm(x2, Lw.w1, gact, Lw.b1, epilogue=EPI_BIAS_GELU, pre_act_out=u)
+    h2 = E(M, d)
+    fo = E(M, d) if keep_ff else None
+    ops.gemm(gact, Lw.w2, h2, Lw.b2, epilogue=EPI_GATED_RES, residual=h1, gate_txt=m2.gate_txt, gate_vid=m2.gate_vid,
+             gate_bstride=m2.bs, S=S, St=St, pre_act_out=fo)
+    if save:
+        a.x1, a.qkv, a.qkh, a.o, a.lse, a.h1, a.u = x1, qkv, qkh, o, lse, h1, u
+        a.x2, a.g, a.ao, a.fo = (x2, gact, ao, fo) if ft is not None else (None, None, None, None)
+    return h2, a
+
+
 # ---------------------------------------------------------------------------------------------------
 def run_forward(model, x, text, t, save: bool, rope=None):
     c = model.config
@@ -138,8 +223,6 @@ def run_forward(model, x, text, t, save: bool, rope=None):
     M = B * S
     dev = x.device
     ft = getattr(model, "fullft", None)
-    KE = d + EXT if st is not None else d        # GEMM reduction length on the LoRA-extended operands
-    r3 = 3 * st.r if st is not None else 0
     E = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
 
     # ---- time embedding + every adaLN modulation of the network in one GEMM ----
@@ -169,52 +252,14 @@ def run_forward(model, x, text, t, save: bool, rope=None):
     if rope is not None:
         rope = (rope[0], rope[1], S, St)
 
+    dims = (B, Fr, C, Hh, Ww, S, St, Sv, M)
+    scratch = SimpleNamespace(xg=E(M, d), gbuf=E(M, c.ff_mult * d))     # transient: norm2 output, GELU output
+    recompute = save and _use_recompute(model, dims)
     saved: List[SimpleNamespace] = []
-    xg = E(M, d)                    # transient: norm2 output
-    gbuf = E(M, c.ff_mult * d)      # transient: GELU output
     for i in range(L):
-        Lw = P.layers[i]
-        m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
-        a = SimpleNamespace(h_in=h)
-        # --- attention branch ---
-        x1 = E(M, d + EXT)
-        a.mean1, a.rstd1 = E(M, dt=torch.float32), E(M, dt=torch.float32)
-        ops.ln_modulate_fwd(h, x1, Lw.n1g, Lw.n1b, (m1.shift_txt, m1.scale_txt, m1.shift_vid, m1.scale_vid, m1.bs),
-                            a.mean1, a.rstd1, d, S, St, c.norm_eps)
-        if st is not None:
-            ops.lora_down(x1, st.a_qkv(st.flat_bf16, i), r3, x1[:, d:], d)
-        qkv = E(M, 3 * d)
-        ops.gemm(x1, Lw.w_qkv, qkv, Lw.b_qkv, K=KE)
-        qkh = E(M, 2 * d)
-        a.qmean, a.qrstd = E(M, 2 * H, dt=torch.float32), E(M, 2 * H, dt=torch.float32)
-        ops.qk_layernorm_fwd(qkv, qkh, Lw.gq, Lw.bq, Lw.gk, Lw.bk, a.qmean, a.qrstd, H, 1e-6, q_scale=Q_PRESCALE, rope=rope)
-        o = E(M, d + EXT)
-        lse = E(B, H, S, dt=torch.float32)
-        qk3, qkv3, o3 = qkh.view(B, S, 2 * d), qkv.view(B, S, 3 * d), o.view(B, S, d + EXT)
-        ops.attn_fwd(qk3[:, :, :d], qk3[:, :, d:], qkv3[:, :, 2 * d:], o3[:, :, :d], lse, B, H, S, q_prescaled=True)
-        if st is not None:
-            ops.lora_down(o, st.a_out(st.flat_bf16, i), st.r, o[:, d:], d)
-        h1 = E(M, d)
-        ao = E(M, d) if (save and ft is not None) else None           # branch output before gating (gate gradient)
-        ops.gemm(o, Lw.w_o, h1, Lw.b_o, epilogue=EPI_GATED_RES, residual=h, gate_txt=m1.gate_txt, gate_vid=m1.gate_vid,
-                 gate_bstride=m1.bs, S=S, St=St, K=KE, pre_act_out=ao)
-        # --- feed-forward branch ---
-        a.mean2, a.rstd2 = E(M, dt=torch.float32), E(M, dt=torch.float32)
-        keep_ff = save and ft is not None                              # dW1 / dW2 need the FF inputs
-        x2 = E(M, d) if keep_ff else xg
-        gact = E(M, c.ff_mult * d) if keep_ff else gbuf
-        ops.ln_modulate_fwd(h1, x2, Lw.n2g, Lw.n2b, (m2.shift_txt, m2.scale_txt, m2.shift_vid, m2.scale_vid, m2.bs),
-                            a.mean2, a.rstd2, d, S, St, c.norm_eps)
-        u = E(M, c.ff_mult * d) if save else gbuf.new_empty(M, c.ff_mult * d)
-        ops.gemm(x2, Lw.w1, gact, Lw.b1, epilogue=EPI_BIAS_GELU, pre_act_out=u)
-        h2 = E(M, d)
-        fo = E(M, d) if keep_ff else None
-        ops.gemm(gact, Lw.w2, h2, Lw.b2, epilogue=EPI_GATED_RES, residual=h1, gate_txt=m2.gate_txt, gate_vid=m2.gate_vid,
-                 gate_bstride=m2.bs, S=S, St=St, pre_act_out=fo)
+        h2, a = block_forward(model, i, h, mod, dims, rope, save and not recompute, scratch)
         if save:
-            a.x1, a.qkv, a.qkh, a.o, a.lse, a.h1, a.u = x1, qkv, qkh, o, lse, h1, u
-            a.x2, a.g, a.ao, a.fo = (x2, gact, ao, fo) if ft is not None else (None, None, None, None)
-            saved.append(a)
+            saved.append(a)         # recompute: only the block input (a.h_in), the rest is rebuilt in the backward pass
         h = h2
 
     # ---- final: norm_final (video rows) -> AdaLayerNorm(shift, scale) -> proj_out -> unpatchify ----
@@ -236,7 +281,7 @@ def run_forward(model, x, text, t, save: bool, rope=None):
     ctx = None
     if save:
         ctx = SimpleNamespace(blocks=saved, mod=mod, h_last=h, y1=y1, fm1=fm1, fr1=fr1, fm2=fm2, fr2=fr2,
-                              dims=(B, Fr, C, Hh, Ww, S, St, Sv, M), f_scale=f_scale, rope=rope)
+                              dims=dims, f_scale=f_scale, rope=rope, recompute=recompute, scratch=scratch if recompute else None)
         if ft is not None:
             ctx.y2, ctx.tsin, ctx.e1_pre, ctx.e1, ctx.emb_pre, ctx.se, ctx.patches, ctx.text = y2, tsin, e1_pre, e1, emb_pre, emb, patches, text
     return out, ctx
@@ -281,6 +326,8 @@ def run_backward(model, ctx, dout: torch.Tensor):
     dh_in = E(M, d)
     for i in reversed(range(L)):
         Lw, a = P.layers[i], ctx.blocks[i]
+        if ctx.recompute:           # rebuild this block's activations from its input
+            _, a = block_forward(model, i, a.h_in, mod, ctx.dims, ctx.rope, True, ctx.scratch)
         m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
         # --- feed-forward branch:  h2 = h1 + gate_ff * W2 gelu(W1 x2 + b1) ---
         ops.gate_mul(dh, tg, m2.gate_txt, m2.gate_vid, m2.bs, d, S, St)

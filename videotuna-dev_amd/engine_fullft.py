@@ -15,7 +15,7 @@ from typing import Callable, Optional
 import torch
 
 from . import ops
-from .engine import _mod, packed
+from .engine import _mod, block_forward, packed
 from .ops import BF16, EPI_DGELU
 
 F32 = torch.float32
@@ -108,6 +108,8 @@ def run_backward_fullft(model, ctx, dout: torch.Tensor, on_grads_ready: Optional
     chain_ws = None if overlapped else ops.attn_bwd_chain_workspace(B, H, S, dev)
     for i in reversed(range(L)):
         Lw, a = P.layers[i], ctx.blocks[i]
+        if ctx.recompute:           # rebuild this block's activations from its input
+            _, a = block_forward(model, i, a.h_in, mod, ctx.dims, ctx.rope, True, ctx.scratch)
         pre = f"transformer_blocks.{i}."
         m1, m2 = _mod(mod, 2 * i, d), _mod(mod, 2 * i + 1, d)
         dm1, dm2 = dm(2 * i), dm(2 * i + 1)

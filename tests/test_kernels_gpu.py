@@ -53,10 +53,11 @@ def test_gemm_bias(dev, M, N, K, gemm_tile):
 
 
 @pytest.mark.parametrize("N", [256, 388])
-def test_gemm_strided_and_epilogues(dev, gemm_tile, N):
+@pytest.mark.parametrize("B,S,St", [(2, 150, 20), (3, 300, 37)], ids=["S150", "S300"])     # S300: a 256-row tile spans two samples
+def test_gemm_strided_and_epilogues(dev, gemm_tile, N, B, S, St):
     from vt355 import ops
     g = torch.Generator().manual_seed(7)
-    B, S, St, K = 2, 150, 20, 128
+    K = 128
     M = B * S
     abig = rb(torch.randn(M, K + 64, generator=g))            # lda > K (extension columns ignored via K=)
     w = rb(torch.randn(N, K, generator=g) * 0.1); bias = rb(torch.randn(N, generator=g))

@@ -232,6 +232,8 @@ __global__ __launch_bounds__(GB_THREADS, 1) void GEMM_BIG_KERNEL(GemmParams p) {
             }
         };
         aux_fetch(0, aux);
+        GateCtx gctx;
+        if (EPI == EPI_GATED_RES) gctx = gate_ctx_load(p, cur.row0, GB_BM, n);
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
             if (wave < 8 && wm == (slab >> 2)) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(GB_THREADS, 1) void GEMM_BIG_KERNEL(GemmParams p) {
                 const int m = cur.row0 + slab * 32 + ml;
                 if (wave < 8 && m < p.M && n < p.N) {
                     const f32x4 v = *(const f32x4*)(Cs + ml * GB_CS_LD + ec);
-                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass]);
+                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass], EPI == EPI_GATED_RES ? &gctx : nullptr);
                 }
             }
             gb_lds_barrier();

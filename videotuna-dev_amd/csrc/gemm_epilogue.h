@@ -35,10 +35,41 @@ __device__ __forceinline__ u32x2 gemm_epilogue_aux_load(const GemmParams& p, int
     return (u32x2){0u, 0u};
 }
 
+// EPI_GATED_RES gates of one output tile, hoisted out of the per-row work: a tile of `rows` <= S rows touches at most the
+// samples b0 = row0 / S and b0 + 1, so their (text, video) gate vectors for this thread's 4 columns are loaded once per
+// tile and a row only selects among them (no per-row integer division, no dependent load).  fast = 0 (S smaller than a
+// tile, or no gates): the generic per-row lookup runs.
+struct GateCtx {
+    f32x4 g[2][2];      // [sample b0, b0+1][text, video]
+    int base0;          // b0 * S
+    int fast;
+};
+__device__ __forceinline__ GateCtx gate_ctx_load(const GemmParams& p, int row0, int rows, int n) {
+    GateCtx c;
+    c.fast = (p.gate_vid != nullptr && p.S >= rows && n < p.N) ? 1 : 0;
+    c.base0 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c.g[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c.fast) {
+        const int b0 = row0 / p.S;
+        const int bl = (p.M - 1) / p.S;                  // last sample
+        const int b1 = b0 + 1 <= bl ? b0 + 1 : bl;
+        c.base0 = b0 * p.S;
+        c.g[0][0] = *(const f32x4*)(p.gate_txt + (size_t)b0 * p.gate_bstride + n);
+        c.g[0][1] = *(const f32x4*)(p.gate_vid + (size_t)b0 * p.gate_bstride + n);
+        c.g[1][0] = *(const f32x4*)(p.gate_txt + (size_t)b1 * p.gate_bstride + n);
+        c.g[1][1] = *(const f32x4*)(p.gate_vid + (size_t)b1 * p.gate_bstride + n);
+    }
+    return c;
+}
+
 // v = accumulators of (row m, columns n..n+3), bias4 = bias of those columns (zeros if none).  Caller guarantees
 // m < M and n < N (N % 4 == 0).
 template <int EPI, bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue_store_aux(const GemmParams& p, int m, int n, f32x4 v, const float* bias4, u32x2 aux) {
+__device__ __forceinline__ void gemm_epilogue_store_aux(const GemmParams& p, int m, int n, f32x4 v, const float* bias4, u32x2 aux,
+                                                        const GateCtx* gc = nullptr) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = v[j] + bias4[j];
@@ -59,7 +90,16 @@ __device__ __forceinline__ void gemm_epilogue_store_aux(const GemmParams& p, int
                     const u32x2 r2 = aux;
                     float r[4] = {__uint_as_float(r2[0] << 16), __uint_as_float(r2[0] & 0xffff0000u),
                                   __uint_as_float(r2[1] << 16), __uint_as_float(r2[1] & 0xffff0000u)};
-                    if (p.gate_vid != nullptr) {
+                    if (gc != nullptr && gc->fast) {
+                        int sr = m - gc->base0;
+                        const bool second = sr >= p.S;
+                        sr -= second ? p.S : 0;
+                        const bool txt = sr < p.St;
+                        const f32x4 ga = txt ? gc->g[0][0] : gc->g[0][1], gb = txt ? gc->g[1][0] : gc->g[1][1];
+                        const f32x4 g4 = second ? gb : ga;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = r[j] + g4[j] * o[j];
+                    } else if (p.gate_vid != nullptr) {
                         const int b = m / p.S;
                         const int s = m - b * p.S;
                         const float* g = (s < p.St ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride + n;

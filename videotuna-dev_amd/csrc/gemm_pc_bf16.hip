@@ -190,6 +190,8 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
             }
         };
         aux_fetch(0, aux);
+        GateCtx gctx;
+        if (EPI == EPI_GATED_RES) gctx = gate_ctx_load(p, cur.row0, GP_BM, n);
         gp_barrier();                        // every multiplier is done reading the stage (the loaders mirror this one too)
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                 const int m = cur.row0 + slab * 32 + ml;
                 if (m < p.M && n < p.N) {
                     const f32x4 v = *(const f32x4*)(Cs + ml * GP_CS_LD + ec);
-                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass]);
+                    gemm_epilogue_store_aux<EPI, OUT_F32>(p, m, n, v, bias4, aux[pass], EPI == EPI_GATED_RES ? &gctx : nullptr);
                 }
             }
             gp_barrier();

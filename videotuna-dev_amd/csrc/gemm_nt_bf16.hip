@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
 // only issue LDS-DMA, two 64-token K-tiles ahead in a three-stage ring of 48 KiB stages:
 //   stage = A columns [0,128) image | A columns [128,256) image | B image, each [64 tokens][256 B] with the nt_swz swizzle.
 // P need only be a multiple of 128: the columns of a ragged last tile beyond P are computed from whatever follows in the
-// rows of A (in bounds; the matrix end reads zeros) and never stored.
+// rows of A (in bounds: the extent ends with the last valid element) and never stored.
 // ------------------------------------------------------------------------------------------------
 #define NTP_STAGE 49152
 static __device__ __forceinline__ void ntp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -161,9 +161,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pc_kernel(GemmNtParams p) {
         const int lw = wave - 4;
         const bf16_t* Ab = p.A + (size_t)m_lo * p.lda;
         const bf16_t* Bb = p.B + (size_t)m_lo * p.ldb;
-        const long long a_bytes = (long long)m_cnt * p.lda * 2, b_bytes = (long long)m_cnt * p.ldb * 2;
-        __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab + p0, (unsigned)((a_bytes - p0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (a_bytes - p0 * 2)));
-        __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb + q0, (unsigned)((b_bytes - q0 * 2) > 0x7fffffffLL ? 0x7fffffffLL : (b_bytes - q0 * 2)));
+        // extents end with the last valid element (row m_cnt - 1, column P - 1 / Q - 1): the operands may be column slices of a
+        // wider tensor, so nothing past that element is touched; rows beyond m_cnt and the tail of a ragged P tile read zeros
+        const long long a_bytes = (((long long)m_cnt - 1) * p.lda + p.P - p0) * 2, b_bytes = (((long long)m_cnt - 1) * p.ldb + p.Q - q0) * 2;
+        __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab + p0, (unsigned)(a_bytes > 0x7fffffffLL ? 0x7fffffffLL : (a_bytes > 0 ? a_bytes : 0)));
+        __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb + q0, (unsigned)(b_bytes > 0x7fffffffLL ? 0x7fffffffLL : (b_bytes > 0 ? b_bytes : 0)));
         // lane l lands at (row l>>4, physical chunk l&15) of its block and fetches logical chunk (l&15) ^ nt_swz(row);
         // nt_swz(4 (lw + 4 j) + drl) does not depend on j, so the block step (16 rows) is a scalar offset
         const int drl = lane >> 4, dcp = lane & 15;

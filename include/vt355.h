@@ -91,6 +91,21 @@ int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float
                      long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                      float softmax_scale, int q_prescaled, void* stream);
 
+/* The same forward with an additive score bias: softmax(q k^T * softmax_scale + bias) v.  bias_t is fp32, TRANSPOSED,
+ * [H][S keys][S queries] (bias_t[h][key][q]), shared by every sample; lse2 as above (bias included).
+ * Replaces: T5Attention's softmax(scores + position_bias) in transformers' T5EncoderModel, the frozen text encoder the
+ * reference calls at cogvideo_pl.py:254-286 / lvdm/modules/encoders/condition.py:81-95 (no scaling there: pass 1.0). */
+int vt_attn_fwd_bias_hd64(const void* q, const void* k, const void* v, const float* bias_t, void* o, float* lse2,
+                          int B, int H, int S,
+                          long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                          long long q_bs, long long k_bs, long long v_bs, long long o_bs,
+                          float softmax_scale, void* stream);
+/* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
+int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
+                    void* stream);
+/* T5DenseGatedActDense activation: y[m,f] = gelu_tanh(u[m,f]) * u[m,F+f]  (u = x [Wi0;Wi1]^T from one fused GEMM) */
+int vt_gated_gelu_bf16(const void* u, long long ldu, void* y, long long ldy, long long M, int F, void* stream);
+
 /* Flash attention backward.  delta_ws: [B*H*S] fp32 workspace; dq_f32: fp32 [.., H*64] accumulation buffer
  * that the CALLER ZEROES beforehand (dQ is summed across key blocks with fp32 atomics); dk, dv bf16.
  * chain_ws / chain_ws_bytes: optional scratch (256-byte aligned, >= vt_attn_bwd_chain_ws_bytes(B,H,S) bytes, contents

@@ -147,3 +147,28 @@ def test_one_full_size_block_train_step(dev, family):
     cos = F.cosine_similarity(gdev, gref, dim=0).item()
     l2 = ((gdev - gref).norm() / gref.norm()).item()
     assert cos > 0.995 and l2 < 0.1, (cos, l2)
+
+
+def test_t5_xxl_layer_fullsize(dev):
+    """One T5 v1.1 XXL encoder layer at its real dimensions (d_model 4096, 64 heads x 64, d_ff 10240; 2 prompts x 226
+    tokens, the CogVideoX text length) against the fp32 CPU oracle on the same bf16-rounded weights; graph replay and
+    launch-by-launch give the same bits."""
+    import t5_oracle as T
+    from vt355.t5 import T5EncoderModel
+    cfg = T.T5Config(num_layers=1, vocab_size=512)
+    m = T5EncoderModel(**vars(cfg)).init_weights(5, std=0.02)
+    with torch.no_grad():        # unit-order score spread, as trained T5 weights have (no 1/sqrt(d_kv) in T5 attention)
+        at = m.encoder.block[0].layer[0].SelfAttention
+        at.q.weight.mul_(0.3); at.k.weight.mul_(0.3)
+    m = m.to(dev)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ids = torch.randint(0, cfg.vocab_size, (2, 226), generator=torch.Generator().manual_seed(1))
+    m.use_graph = False
+    out0 = m(ids.to(dev))[0]
+    m.use_graph = True
+    out1 = m(ids.to(dev))[0]
+    out2 = m(ids.to(dev))[0]
+    assert torch.equal(out0, out1) and torch.equal(out1, out2)
+    ref = T.encoder_forward(P, cfg, ids)
+    err = (out1.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-2, err

@@ -279,3 +279,51 @@ def test_encoder_prefetcher_sequencing():
     assert [x for x in log if x[0] == "enc"] == [("enc", i) for i in range(5)]
     with pytest.raises(ValueError):
         EncoderPrefetcher([], encode, depth=0)
+
+
+def test_t5_encoder_host_side(tmp_path):
+    """HF key names / shapes of the T5 encoder, the sharded safetensors loader, the reflection remap of the reference's
+    cond_stage_config, the bucket table against the oracle -- and no CPU path."""
+    import json
+    import sys
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import t5_oracle as T
+    from vt355.config import get_obj_from_str
+    from vt355.t5 import FrozenT5Embedder, T5EncoderModel, relative_position_bucket
+    cfg = T.tiny_config()
+    m = T5EncoderModel(**vars(cfg)).init_weights(3)
+    want = T.init_params(cfg, 0)
+    got = m.state_dict()
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(v.shape), k
+    rel = torch.arange(-300, 300)
+    assert torch.equal(relative_position_bucket(rel, 32, 128), T.relative_position_bucket(rel, 32, 128))
+    # sharded HF layout round trip (+ the tied embed_tokens alias the checkpoints carry)
+    root = tmp_path / "text_encoder"
+    root.mkdir()
+    (root / "config.json").write_text(json.dumps(dict(vars(cfg), feed_forward_proj="gated-gelu", model_type="t5", is_encoder_decoder=False)))
+    keys = sorted(got)
+    half = len(keys) // 2
+    shards = {"model-00001-of-00002.safetensors": keys[:half], "model-00002-of-00002.safetensors": keys[half:]}
+    wm = {}
+    for fn, ks in shards.items():
+        sd = {k: got[k].contiguous() for k in ks}
+        if "shared.weight" in sd:
+            sd["encoder.embed_tokens.weight"] = sd["shared.weight"].clone()
+            wm["encoder.embed_tokens.weight"] = fn
+        save_file(sd, str(root / fn))
+        wm.update({k: fn for k in ks})
+    (root / "model.safetensors.index.json").write_text(json.dumps({"weight_map": wm}))
+    m2 = T5EncoderModel.from_pretrained(str(tmp_path), subfolder="text_encoder")
+    for k, v in got.items():
+        assert torch.equal(m2.state_dict()[k], v), k
+    assert get_obj_from_str("videotuna.models.lvdm.modules.encoders.condition.FrozenT5Embedder") is FrozenT5Embedder
+    emb = FrozenT5Embedder(tokenizer=lambda text, **kw: {"input_ids": torch.zeros(len(text), kw["max_length"], dtype=torch.long)},
+                           transformer=m, device="cpu", max_length=12)
+    assert not any(p.requires_grad for p in emb.parameters())
+    with pytest.raises((ValueError, RuntimeError)):          # host tensors: the kernels have no CPU path
+        emb(["a prompt"])
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, dtype=torch.long), attention_mask=torch.ones(1, 4))

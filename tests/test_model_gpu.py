@@ -238,3 +238,24 @@ def test_block_recompute_gives_the_same_gradients(dev, mode):
     assert rel < 1e-3, rel
     with pytest.raises(ValueError):
         model.enable_gradient_checkpointing("sometimes")
+
+
+@pytest.mark.parametrize("S", [150, 226])
+def test_t5_encoder_matches_oracle(dev, S):
+    """The frozen text encoder on the vt355 kernels (rmsnorm, fused QKV / wi GEMMs, attention with the relative position
+    bias, gated GELU) against oracle/t5_oracle.py -- itself pinned to transformers' T5EncoderModel by tests/golden/t5_tiny.npz.
+    bf16 storage vs the fp64 oracle on the bf16-rounded weights."""
+    import t5_oracle as T
+    from vt355.t5 import T5EncoderModel
+    cfg = T.tiny_config(num_layers=3, num_heads=4, d_model=256, d_ff=512)
+    m = T5EncoderModel(**vars(cfg)).init_weights(7).to(dev)
+    P = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(S)
+    ids = torch.randint(0, cfg.vocab_size, (2, S), generator=g)
+    out = m(ids.to(dev))
+    assert out[0] is out.last_hidden_state and tuple(out[0].shape) == (2, S, cfg.d_model)
+    ref = T.encoder_forward(P, cfg, ids)
+    err = (out[0].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-2, err
+    cos = torch.nn.functional.cosine_similarity(out[0].double().cpu().reshape(-1), ref.reshape(-1), dim=0).item()
+    assert cos > 0.9995, cos

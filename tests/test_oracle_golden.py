@@ -144,3 +144,22 @@ def test_rope_block_is_orthogonal_and_position_relative():
     # tokens (t, 0, 0) are rows 4t: <R_t q, R_{t+2} k> must not depend on t
     dots = [float(rq[4 * t] @ rk[4 * (t + 2)]) for t in range(4)]
     assert max(dots) - min(dots) < 1e-5
+
+
+def test_t5_oracle_matches_transformers_golden():
+    """oracle/t5_oracle.py against the output of transformers' own T5EncoderModel on seeded weights
+    (tests/golden/make_golden_t5.py): the whole encoder and the bucketed relative position bias (150 tokens > max_distance,
+    so exact, log-spaced and clamped buckets all occur)."""
+    import t5_oracle as T
+    g = np.load(os.path.join(G, "t5_tiny.npz"))
+    cfg = T.tiny_config()
+    P = {k[2:]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith("P.")}
+    ids = torch.from_numpy(g["ids"])
+    out = T.encoder_forward(P, cfg, ids)
+    ref = torch.from_numpy(g["out"]).double()
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    bias = T.position_bias(P["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], ids.shape[1], cfg)
+    assert torch.equal(bias.float(), torch.from_numpy(g["bias"]))
+    # bucketing known answers: 0 -> 0, +1 -> 17, -1 -> 1, far left / right clamp to 15 / 31
+    rel = torch.tensor([0, 1, -1, 7, -8, 200, -200])
+    assert T.relative_position_bucket(rel, 32, 128).tolist() == [0, 17, 1, 23, 8, 31, 15]

@@ -112,6 +112,44 @@ def main():
             m1, _ = timeit(lambda: ops.gemm(a2, w3, o2, b2, epilogue=ops.EPI_GATED_RES, residual=res_, gate_txt=gt, gate_vid=gv,
                                             gate_bstride=1920, S=S, St=226))
             print(f"proj K={K_}: plain {m0:.3f} ms {fl2/m0/1e9:.0f} TF/s | +gated residual {m1:.3f} ms {fl2/m1/1e9:.0f}", flush=True)
+    if "t5" in which:         # the frozen text encoder at T5 v1.1 XXL size (random weights), 2 prompts x 226 tokens
+        from vt355.t5 import T5EncoderModel
+        with torch.device(dev):
+            m = T5EncoderModel()
+        gw = torch.Generator(device=dev).manual_seed(1)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                # q / k weights scaled so that the unscaled scores q.k have unit-order spread (trained T5 weights do: the
+                # 1/sqrt(d_kv) is folded into its initialisation); at 0.02 the softmax is one-hot and any two bf16
+                # implementations disagree chaotically
+                p_.normal_(0.0, 0.006 if (".q.weight" in n_ or ".k.weight" in n_) else 0.02, generator=gw)
+                if n_.endswith("layer_norm.weight"):
+                    p_.add_(1.0)
+        ids = torch.randint(0, 32128, (2, 226), device=dev)
+        nparam = sum(p_.numel() for n_, p_ in m.named_parameters() if n_ != "shared.weight")
+        m.use_graph = False
+        med0, _ = timeit(lambda: m(ids), iters=5, warm=2)
+        print(f"T5-XXL encoder fwd, 2 x 226 tokens, launch by launch: {med0:.2f} ms", flush=True)
+        m.use_graph = True
+        med, mn = timeit(lambda: m(ids), iters=5, warm=2)
+        print(f"T5-XXL encoder fwd, 2 x 226 tokens, HIP graph replay: {med:.2f} ms (min {mn:.2f})  weights streamed {nparam*2/1e9:.1f} GB -> {nparam*2/med/1e6:.0f} GB/s, "
+              f"{2.0*nparam*452/med/1e9:.0f} TFLOP/s", flush=True)
+        try:                      # calibration only: transformers' own module on the same device
+            import transformers
+            sd = {k: v for k, v in m.state_dict().items()}
+            with torch.device(dev):
+                hf = transformers.T5EncoderModel(transformers.T5Config(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24,
+                                                                       num_heads=64, feed_forward_proj="gated-gelu", dropout_rate=0.0)).to(BF).eval()
+            hf.load_state_dict(sd, strict=False)
+            with torch.no_grad():
+                ref = hf(input_ids=ids)[0]
+                out = m(ids)[0]
+                print(f"   vs transformers {transformers.__version__} bf16 on the same weights: max |diff| {(out.float()-ref.float()).abs().max().item():.3f} "
+                      f"of max |ref| {ref.float().abs().max().item():.3f}", flush=True)
+                med2, _ = timeit(lambda: hf(input_ids=ids), iters=5, warm=2)
+            print(f"   transformers T5EncoderModel bf16 (eager, rocBLAS/hipBLASLt): {med2:.2f} ms", flush=True)
+        except Exception as e:
+            print("   transformers calibration unavailable:", repr(e)[:200], flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

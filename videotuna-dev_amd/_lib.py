@@ -34,6 +34,9 @@ PROTOTYPES = {
     "vt_small_linear_bwd": [_fp, _i, _vp, _i, _vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp],
     "vt_silu_bwd": [_fp, _vp, _fp, _ll, _vp],
     "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
+    "vt_attn_fwd_bias_hd64": [_vp, _vp, _vp, _fp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+    "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],
+    "vt_gated_gelu_bf16": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
                          _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp, _ll, _vp],
     "vt_attn_bwd_chain_ws_bytes": [_i, _i, _i],

@@ -15,6 +15,8 @@ TARGET_REMAP = {
     "peft.LoraConfig": "vt355.lora.LoraConfig",
     "videotuna.models.cogvideo_hf.cogvideo_pl.CogVideoXWorkFlow": "vt355.workflow.CogVideoXWorkFlow",
     "videotuna.models.cogvideo_hf.cogvideo_i2v.CogVideoXI2V": "vt355.workflow.CogVideoXI2V",
+    "videotuna.models.lvdm.modules.encoders.condition.FrozenT5Embedder": "vt355.t5.FrozenT5Embedder",
+    "transformers.T5EncoderModel": "vt355.t5.T5EncoderModel",
 }
 _NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
 

@@ -29,6 +29,7 @@ struct AttnFwdParams {
     long long q_rs, k_rs, v_rs, o_rs;
     long long q_bs, k_bs, v_bs, o_bs;
     float scale_log2;
+    const float* bias_t;   // BIAS kernels: additive score bias, TRANSPOSED [H][S keys][S queries] fp32 (same for every sample), or null
 };
 
 #ifndef VT_FWD_WAVES
@@ -41,7 +42,9 @@ struct AttnFwdParams {
 #define NEG_BIG (-1.0e30f)
 #define LAZY_THR 8.0f
 
-template <bool PRESCALED>
+// BIAS (T5 relative position bias; SURVEY 8(f) row 1, the frozen text encoder): scores get bias[h][q][key] added before the
+// softmax.  The table is read transposed so that the 32 lanes of a half-wave (consecutive queries) load consecutive words.
+template <bool PRESCALED, bool BIAS = false>
 __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn_fwd_hd64_kernel(AttnFwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[32768];   // 2 x (K 8 KiB + V 8 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,6 +232,20 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
                 st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt2], 0, 0, 0);
             }
         }
+        if constexpr (BIAS) {
+            int qc = q0 + r;
+            qc = qc < p.S ? qc : p.S - 1;
+            const float* bp = p.bias_t + ((size_t)head * p.S) * p.S + qc;
+            const float isc = 1.0f / sc * 1.4426950408889634f;        // the bias is in score units: (s*scale + bias) * log2e
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int key = t * FK + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    key = key < p.S ? key : p.S - 1;
+                    st[kt2][i] += bp[(size_t)key * p.S] * isc;
+                }
+        }
         // ---- mask the ragged last tile ----
         if ((t + 1) * FK > p.S) {
 #pragma unroll
@@ -325,8 +342,35 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
     p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs;
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    p.bias_t = nullptr;
     const int nqt = (S + FQ - 1) / FQ;
     if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// Same kernel with an additive score bias (fp32, transposed [H][S][S]: bias_t[h][key][q]), softmax(q k^T * scale + bias) v.
+// Used by the frozen T5 text encoder (relative position bias, no scaling: softmax_scale = 1); no lse output is needed there
+// lse2 is written as in vt_attn_fwd_hd64 (bias included).
+extern "C" int vt_attn_fwd_bias_hd64(const void* q, const void* k, const void* v, const float* bias_t, void* o, float* lse2,
+                                     int B, int H, int S,
+                                     long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                                     long long q_bs, long long k_bs, long long v_bs, long long o_bs,
+                                     float softmax_scale, void* stream) {
+    if (B <= 0 || H <= 0 || S <= 0 || bias_t == nullptr || lse2 == nullptr || !(softmax_scale > 0.f)) return VT_ERR_BAD_SHAPE;
+    if ((q_rs % 8) || (k_rs % 8) || (v_rs % 8) || (o_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4))
+        return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return VT_ERR_BAD_ALIGN;
+    if ((((uintptr_t)o) & 7) || (((uintptr_t)bias_t) & 3)) return VT_ERR_BAD_ALIGN;
+    if ((long long)S * k_rs * 2 >= 0x7fffffffLL || (long long)S * v_rs * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    AttnFwdParams p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse2 = lse2;
+    p.S = S; p.H = H; p.B = B;
+    p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
+    p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    p.bias_t = bias_t;
+    const int nqt = (S + FQ - 1) / FQ;
+    hipLaunchKernelGGL((attn_fwd_hd64_kernel<false, true>), dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -177,6 +177,33 @@ def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = 
           "vt_attn_fwd_hd64")
 
 
+def attn_fwd_bias(q, k, v, bias_t, o, lse2, B: int, H: int, S: int, scale: float = 1.0):
+    """softmax(q k^T * scale + bias) v; bias_t fp32 [H, S(keys), S(queries)] contiguous, shared by all samples (T5)."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _req(t, BF16, n, 3)
+    _req(bias_t, torch.float32, "bias_t", 3)
+    if tuple(bias_t.shape) != (H, S, S) or not bias_t.is_contiguous():
+        raise ValueError(f"bias_t must be contiguous [{H}, {S}, {S}], got {tuple(bias_t.shape)}")
+    check(load_library().vt_attn_fwd_bias_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias_t.data_ptr(), o.data_ptr(),
+                                               lse2.data_ptr(), B, H, S, q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+                                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, _stream()),
+          "vt_attn_fwd_bias_hd64")
+
+
+def rmsnorm(x, w, y, eps: float = 1e-6):
+    """T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w (rows of a 2-d bf16 tensor)"""
+    _req(x, BF16, "x", 2); _req(y, BF16, "y", 2); _req(w, BF16, "w", 1)
+    check(load_library().vt_rmsnorm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), y.data_ptr(), y.stride(0), x.shape[0], x.shape[1],
+                                         eps, _stream()), "vt_rmsnorm_bf16")
+
+
+def gated_gelu(u, y):
+    """y[:, f] = gelu_tanh(u[:, f]) * u[:, F + f] with F = y.shape[1]"""
+    _req(u, BF16, "u", 2); _req(y, BF16, "y", 2)
+    check(load_library().vt_gated_gelu_bf16(u.data_ptr(), u.stride(0), y.data_ptr(), y.stride(0), u.shape[0], y.shape[1], _stream()),
+          "vt_gated_gelu_bf16")
+
+
 def attn_bwd_chain_workspace(B: int, H: int, S: int, device) -> Optional[torch.Tensor]:
     """scratch for the dQ hand-off chains of vt_attn_bwd_hd64 (None when the library runs without chains); one buffer
     serves every attention-backward launch of a step"""

@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--model", choices=["2b", "5b"], default="2b",
                     help="2b = the benchmark (BASELINE configs[1]); 5b = CogVideoX-5B dimensions (48 heads, 42 layers, rotary q/k) -- "
                          "extra data point, labelled as such, never the headline line")
+    ap.add_argument("--text-encoder", action="store_true",
+                    help="extra data point: the frozen T5-XXL encoder (vt355.t5, random weights) produces every micro-batch's text "
+                         "embeddings inside the loop, one step ahead on a side stream (SURVEY 8(f) row 1); default: pre-encoded text")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
     args = ap.parse_args()
@@ -114,9 +117,30 @@ def main():
     B, Fr, C, Hh, Ww, St = args.micro_batch, 13, 16, 60, 90, 226
     dgen = torch.Generator(device=dev).manual_seed(20230211 + rank)      # per-rank data / in-step RNG
 
+    t5 = side = None
+    if args.text_encoder:
+        from vt355.t5 import T5EncoderModel
+        with torch.device(dev):
+            t5 = T5EncoderModel()                       # T5 v1.1 XXL dimensions
+        with torch.no_grad():
+            for name, p in t5.named_parameters():
+                p.normal_(0.0, 0.006 if (".q.weight" in name or ".k.weight" in name) else 0.02, generator=gen)
+                if name.endswith("layer_norm.weight"):
+                    p.add_(1.0)
+        side = torch.cuda.Stream(device=dev)
+
     def make_batch():
         x0 = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
-        text = (torch.randn(B, St, 4096, device=dev, generator=dgen) * 0.2).to(torch.bfloat16)
+        if t5 is not None:                              # token ids -> frozen encoder on the side stream; the DiT waits on the event
+            ids = torch.randint(0, 32128, (B, St), device=dev, generator=dgen)
+            side.wait_stream(torch.cuda.current_stream())
+            ids.record_stream(side)                     # allocated on the main stream, consumed on the side stream
+            with torch.cuda.stream(side):
+                text = t5(ids)[0]
+                ev = torch.cuda.Event(); ev.record(side)
+            text = (text, ev)
+        else:
+            text = (torch.randn(B, St, 4096, device=dev, generator=dgen) * 0.2).to(torch.bfloat16)
         noise = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
         t = torch.randint(0, 1000, (B,), device=dev, generator=dgen)
         return x0, text, noise, t
@@ -126,9 +150,16 @@ def main():
 
     def step():
         nonlocal batches
+        nxt = None
+        if t5 is not None:                        # the NEXT step's prompts are encoded while this step's DiT runs
+            nxt = [make_batch() for _ in range(args.accum)]
         opt.zero_grad()
         for mb in range(args.accum):
             x0, text, noise, t = batches[mb]
+            if isinstance(text, tuple):
+                text, ev = text
+                torch.cuda.current_stream().wait_event(ev)
+                text.record_stream(torch.cuda.current_stream())
             noisy = sched.add_noise(x0, noise, t)
             out = peft(hidden_states=noisy, encoder_hidden_states=text, timestep=t, image_rotary_emb=rope, return_dict=False)[0]
             sa, sb, w = sched.coefficients(t)
@@ -139,7 +170,7 @@ def main():
             losses.append(loss.detach())
         if args.mode == "lora":
             red.reduce_async()                    # one RCCL all-reduce of the flat LoRA gradient ...
-        batches = [make_batch() for _ in range(args.accum)]   # ... overlapped with the next step's input generation
+        batches = nxt if nxt is not None else [make_batch() for _ in range(args.accum)]   # ... overlapped with the next step's input generation
         if args.mode == "lora":
             red.wait()
         else:
@@ -214,7 +245,9 @@ def main():
                        "micro_batch": args.micro_batch, "accumulate_grad_batches": args.accum,
                        "global_batch": world * args.micro_batch * args.accum, "seq_len": S, "layers": model.config.num_layers,
                        "parallelism": f"dp{world}", "recompute": recompute_note,
-                       "weights": "seeded random init (no checkpoints offline)"},
+                       "weights": "seeded random init (no checkpoints offline)",
+                       "text": ("T5-XXL encoder (vt355.t5, random weights) in the loop, one step ahead on a side stream"
+                                if args.text_encoder else "pre-encoded prompt embeddings (synthetic)")},
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_summary.json; "

@@ -46,6 +46,9 @@ class EncoderPrefetcher:
                 return self.encode(raw), None
         main = torch.cuda.current_stream(self.device)
         self.side.wait_stream(main)                # inputs produced on the main stream (e.g. H2D copies) are visible
+        for t in _tensors(raw):
+            if t.is_cuda:
+                t.record_stream(self.side)         # ... and must not be recycled by the allocator before the side stream read them
         with torch.cuda.stream(self.side), torch.no_grad():
             out = self.encode(raw)
             ev = torch.cuda.Event()

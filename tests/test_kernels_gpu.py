@@ -431,5 +431,58 @@ def test_abi_rejects_bad_arguments(dev):
     with pytest.raises(VtError, match="vt_attn_bwd_set_chain"):      # persistent grid must be a multiple of 8 slots
         ops.attn_bwd_set_chain(0, 12)
     ops.attn_bwd_set_chain(0, 0)
+    with pytest.raises(VtError, match="vt_rmsnorm_bf16"):           # rows of 8-element chunks
+        ops.rmsnorm(a[:, :60], w[0, :60], out[:, :60])
+    with pytest.raises(VtError, match="vt_gated_gelu_bf16"):        # u must hold both halves
+        ops.gated_gelu(a, torch.zeros(64, 128, dtype=BF, device=dev))
     with pytest.raises((VtError, TypeError, ValueError)):            # host tensors are refused: there is no CPU path
         ops.gemm(a.cpu(), w.cpu(), out.cpu(), None)
+
+
+# ------------------------------------------------------------------ frozen T5 text encoder kernels
+@pytest.mark.parametrize("M,D", [(5, 64), (452, 4096), (300, 1032)])
+def test_rmsnorm(dev, M, D):
+    """T5LayerNorm (transformers modeling_t5.T5LayerNorm): x * rsqrt(mean(x^2) + eps) * w, fp32 statistics, strided rows"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + D)
+    xb = rb(torch.randn(M, D + 8, generator=g) * 3.0); w = rb(1.0 + 0.2 * torch.randn(D, generator=g))
+    x = xb[:, :D]
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    X = xb.to(dev, BF)
+    y = torch.full((M, D + 16), 9.0, dtype=BF, device=dev)
+    ops.rmsnorm(X[:, :D], w.to(dev, BF), y[:, :D], 1e-6)
+    close(y[:, :D], ref, 1e-2, 1e-2, "rmsnorm"); assert (y[:, D:] == 9).all()
+
+
+def test_gated_gelu(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(4)
+    M, Fd = 123, 264
+    u = rb(torch.randn(M, 2 * Fd + 8, generator=g) * 2.0)
+    ref = F.gelu(u[:, :Fd], approximate="tanh") * u[:, Fd:2 * Fd]
+    y = torch.empty(M, Fd, dtype=BF, device=dev)
+    ops.gated_gelu(u.to(dev, BF), y)
+    close(y, ref, 1e-2, 1e-2, "gated gelu")
+
+
+@pytest.mark.parametrize("B,H,S,scale", [(2, 3, 226, 1.0), (1, 2, 77, 0.125), (1, 1, 300, 1.0)])
+def test_attn_fwd_bias(dev, B, H, S, scale):
+    """softmax(q k^T * scale + bias) v against fp32 torch, bias given transposed [H, key, query] (T5Attention: scale 1, bias =
+    relative position table, no mask); ragged S; lse2 = log2 sum exp of the biased scores"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(S)
+    d = H * 64
+    qkv = rb(torch.randn(B, S, 3 * d, generator=g) * (0.35 if scale == 1.0 else 1.0))
+    bias = torch.randn(H, S, S, generator=g) * 2.0                       # [h, query, key]
+    q, k, v = [qkv[:, :, i * d:(i + 1) * d].view(B, S, H, 64).transpose(1, 2) for i in range(3)]
+    s = q @ k.transpose(-1, -2) * scale + bias[None]
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, d)
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634
+    dqkv = qkv.to(dev, BF)
+    o = torch.empty(B, S, d, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+    bias_t = bias.transpose(1, 2).contiguous().to(dev)
+    ops.attn_fwd_bias(dqkv[:, :, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], bias_t, o, lse, B, H, S, scale)
+    close(o, ref, 2e-2, 2e-2, "attention with bias")
+    close(lse, lse_ref, 1e-3, 2e-2, "lse2 with bias")
+    with pytest.raises(ValueError):
+        ops.attn_fwd_bias(dqkv[:, :, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], bias_t[:, :, :-1].contiguous(), o, lse, B, H, S, scale)

@@ -100,6 +100,14 @@ int vt_attn_fwd_bias_hd64(const void* q, const void* k, const void* v, const flo
                           long long q_rs, long long k_rs, long long v_rs, long long o_rs,
                           long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                           float softmax_scale, void* stream);
+/* Split-K C_f32[M,N] = A[M,K] W[N,K]^T for a few hundred rows against a large weight (the T5 encoder at 2 x 226 tokens): the K range
+ * is cut into `splits` pieces (a divisor of K/64; <= 0: chosen so that tiles x splits fills the CUs) whose partial tiles are added
+ * into C with fp32 atomics; C is zeroed by the call.  vt_residual_cast_bf16: out = bf16(acc (+ R)), the finishing pass.
+ * Replaces: the `o` / `wo` nn.Linear of transformers' T5Attention / T5DenseGatedActDense + the residual add of T5LayerSelfAttention /
+ * T5LayerFF (modeling_t5.py), reached from cogvideo_pl.py:254-286. */
+int vt_gemm_splitk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int splits, void* stream);
+int vt_residual_cast_bf16(const float* acc, long long lda, const void* R, long long ldr, void* out, long long ldo, long long M, int N,
+                          void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);

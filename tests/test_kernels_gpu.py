@@ -486,3 +486,23 @@ def test_attn_fwd_bias(dev, B, H, S, scale):
     close(lse, lse_ref, 1e-3, 2e-2, "lse2 with bias")
     with pytest.raises(ValueError):
         ops.attn_fwd_bias(dqkv[:, :, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:], bias_t[:, :, :-1].contiguous(), o, lse, B, H, S, scale)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(452, 4096, 4096, 0), (452, 512, 10240, 5), (100, 256, 1024, 2), (300, 384, 512, 1)])
+def test_gemm_splitk_and_residual_cast(dev, M, N, K, splits):
+    """few rows x large weight: K range split over the persistent producer / consumer kernel, fp32 atomics, finishing pass"""
+    from vt355 import ops
+    from vt355._lib import VtError
+    g = torch.Generator().manual_seed(M + N + K)
+    a = rb(torch.randn(M, K + 64, generator=g)); w = rb(torch.randn(N, K, generator=g) * 0.05); r = rb(torch.randn(M, N, generator=g))
+    ref = a[:, :K] @ w.T
+    acc = torch.full((M, N), 7.0, device=dev)
+    ops.gemm_splitk(a.to(dev, BF)[:, :K], w.to(dev, BF), acc, splits)
+    close(acc, ref, 2e-3, 2e-3 * ref.abs().max().item(), "split-K accumulate")
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.residual_cast(acc, r.to(dev, BF), out)
+    close(out, ref + r, 1e-2, 1e-2 * ref.abs().max().item(), "residual + cast")
+    ops.residual_cast(acc, None, out)
+    close(out, ref, 1e-2, 1e-2 * ref.abs().max().item(), "cast")
+    with pytest.raises(VtError, match="vt_gemm_splitk_f32"):         # splits must divide K / 64
+        ops.gemm_splitk(a.to(dev, BF)[:, :K], w.to(dev, BF), acc, 7 if (K // 64) % 7 else 9)

@@ -127,6 +127,12 @@ def main():
                     p_.add_(1.0)
         ids = torch.randint(0, 32128, (2, 226), device=dev)
         nparam = sum(p_.numel() for n_, p_ in m.named_parameters() if n_ != "shared.weight")
+        for mode in (1, 3):     # which GEMM tiling streams cold weights best at M = 452 (the default picks by shape)
+            ops.gemm_set_tile(mode)
+            m.use_graph = False
+            medm, _ = timeit(lambda: m(ids), iters=3, warm=1)
+            print(f"T5-XXL encoder fwd with vt_gemm_set_tile({mode}): {medm:.2f} ms", flush=True)
+        ops.gemm_set_tile(0)
         m.use_graph = False
         med0, _ = timeit(lambda: m(ids), iters=5, warm=2)
         print(f"T5-XXL encoder fwd, 2 x 226 tokens, launch by launch: {med0:.2f} ms", flush=True)

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "vt_silu_bwd": [_fp, _vp, _fp, _ll, _vp],
     "vt_attn_fwd_hd64": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _i, _vp],
     "vt_attn_fwd_bias_hd64": [_vp, _vp, _vp, _fp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
+    "vt_gemm_splitk_f32": [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _i, _vp],
+    "vt_residual_cast_bf16": [_fp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],
     "vt_gated_gelu_bf16": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,

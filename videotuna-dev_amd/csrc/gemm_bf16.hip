@@ -220,6 +220,9 @@ static int VT_CAT(pick_tile, VT_SUFFIX)(int M, int N, int K) {
     const long long tpc = (long long)((M + 255) / 256) * ((N + 127) / 128);
     if (N >= 6144 && t256 >= 512) return 2;
     if (tpc >= 512 && K >= 512) return 3;
+    // a few hundred rows against a large weight (the frozen T5 encoder: 452 x [4096 .. 20480] x [4096 .. 10240]): the weights
+    // come from HBM, not the L2, and the producer / consumer ring keeps two K-tiles in flight per CU (11.5 -> 10.0 ms per T5 forward)
+    if (M > 64 && M <= 1024 && (long long)N * K >= (1LL << 24)) return 3;
     return 1;
 }
 
@@ -236,7 +239,7 @@ extern "C" int GEMM_ENTRY(const void* A, int lda, const void* W, int ldw, void* 
     p.R = (const bf16_t*)R; p.gate_txt = gate_txt; p.gate_vid = gate_vid;
     p.C2 = (bf16_t*)C2; p.U = (const bf16_t*)U;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.ldc2 = ldc2; p.ldu = ldu;
-    p.S = S > 0 ? S : 1; p.St = St; p.gate_bstride = gate_bstride; p.r_mod = r_mod;
+    p.S = S > 0 ? S : 1; p.St = St; p.gate_bstride = gate_bstride; p.r_mod = r_mod; p.splits = 1;
     hipStream_t st = (hipStream_t)stream;
     const int tile = VT_CAT(pick_tile, VT_SUFFIX)(M, N, K);
     const bool big = tile == 2;

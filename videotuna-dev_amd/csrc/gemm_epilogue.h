@@ -17,6 +17,7 @@ struct GemmParams {
     int lda, ldw, ldc, ldr, ldc2, ldu;
     int S, St, gate_bstride;  // rows per sample, text rows per sample, gate batch stride (elements)
     int r_mod;                // if > 0 the residual row is (m % r_mod)  (positional table add)
+    int splits;               // producer / consumer kernel only: > 1 = split-K, partial tiles added into an fp32 C with atomics
 };
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_DGELU = 3 };
@@ -118,6 +119,12 @@ __device__ __forceinline__ void gemm_epilogue_store_aux(const GemmParams& p, int
                     for (int j = 0; j < 4; ++j) o[j] = o[j] * gelu_tanh_grad_f(u[j]);
                 }
                 if (OUT_F32) {
+                    if (p.splits > 1) {            // split-K partial tile: C was zeroed by the host entry point
+                        float* c = (float*)p.C + (size_t)m * p.ldc + n;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(c + j, o[j]);
+                        return;
+                    }
                     *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
                 } else {
                     u32x2 c2;

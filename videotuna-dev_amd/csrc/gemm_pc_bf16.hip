@@ -67,10 +67,14 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
     const int nbm = (p.M + GP_BM - 1) / GP_BM, nbn = (p.N + GP_BN - 1) / GP_BN;
-    const int ntiles = nbm * nbn;
+    // split-K (p.splits > 1, fp32 C, EPI_BIAS only; the host guarantees (K / 64) % splits == 0): a work item is (output tile,
+    // K range); item w = tile w % ntiles_mn of split w / ntiles_mn, so the workgroups that run together share one K range of A
+    const int ntiles_mn = nbm * nbn;
+    const int splits = p.splits > 1 ? p.splits : 1;
+    const int ntiles = ntiles_mn * splits;       // work items
     const int spx = gridDim.x >> 3;
     const int slot = (int)(blockIdx.x & 7) * spx + (int)(blockIdx.x >> 3);
-    const int nk = p.K / GP_BK;
+    const int nk = p.K / GP_BK / splits;         // K-tiles per work item
     if (slot >= ntiles) return;
     const int my_tiles = (ntiles - slot + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_kt = my_tiles * nk;          // K-tiles this workgroup streams, over all its output tiles
@@ -87,11 +91,12 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
         const int a_voff0 = row0p * p.lda * 2 + ((dcp ^ sw) << 4);
         const int w_voff0 = row0p * p.ldw * 2 + ((dcp ^ sw) << 4);
         const int a_pstep = 32 * p.lda * 2, w_pstep = 32 * p.ldw * 2;
-        GpTile cur = gp_tile(p, slot, nbm, nbn);
+        GpTile cur = gp_tile(p, slot % ntiles_mn, nbm, nbn);
         int tile = slot, kt = 0;
+        int kbase = (slot / ntiles_mn) * nk;
         auto issue = [&](int g) {                // K-tile number g of the stream -> stage g % 3
             __amdgpu_buffer_rsrc_t ra = make_rsrc(cur.a, cur.a_bytes), rw = make_rsrc(cur.w, cur.w_bytes);
-            const int soff = kt * GP_BK * 2;
+            const int soff = (kbase + kt) * GP_BK * 2;
             char* st = smem + (g % GP_NS) * GP_STAGE + lw * 1024;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
             if (++kt == nk) {                    // next K-tile belongs to the next output tile
                 kt = 0;
                 tile += gridDim.x;
-                if (tile < ntiles) cur = gp_tile(p, tile, nbm, nbn);
+                if (tile < ntiles) { cur = gp_tile(p, tile % ntiles_mn, nbm, nbn); kbase = (tile / ntiles_mn) * nk; }
             }
         };
         int issued = 0;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
     const int ec = (tid & 31) * 4;        // first of this thread's 4 columns
     int g = 0;
     for (int tile = slot; tile < ntiles; tile += gridDim.x) {
-        const GpTile cur = gp_tile(p, tile, nbm, nbn);
+        const GpTile cur = gp_tile(p, tile % ntiles_mn, nbm, nbn);
         // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
         // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
         f32x16 acc[2][4];
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
         float* Cs = (float*)(smem + ((g - 1) % GP_NS) * GP_STAGE);
         const int n = cur.col0 + ec;
         float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr && n < p.N) {
+        if (p.bias != nullptr && n < p.N && tile < ntiles_mn) {      // split-K: only the first K range adds the bias
 #pragma unroll
             for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
         }
@@ -233,7 +238,7 @@ static int VT_CAT(launch_pc, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         slots = cus >= 8 ? cus / 8 * 8 : 8;
     }
-    const int ntiles = nbm * nbn;
+    const int ntiles = nbm * nbn * (p.splits > 1 ? p.splits : 1);
     const int grid = ntiles < slots ? (ntiles + 7) / 8 * 8 : slots;
     hipLaunchKernelGGL((GEMM_PC_KERNEL<EPI, F32>), dim3(grid), dim3(512), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
@@ -249,4 +254,35 @@ int VT_CAT(vt_gemm_pc_dispatch, VT_SUFFIX)(const GemmParams& p, int epilogue, in
         case EPI_DGELU: return VT_CAT(launch_pc, VT_SUFFIX)<EPI_DGELU, false>(p, st);
         default: return VT_ERR_UNSUPPORTED;
     }
+}
+
+// Split-K GEMM for a few hundred rows against a large weight (M <= ~1024: the frozen T5 encoder, 2 x 226 tokens): the output has
+// too few 256 x 128 tiles to occupy the chip and the weights stream from HBM, so the K range is cut into `splits` pieces that
+// run as separate work items of the persistent producer / consumer kernel and add their partial tiles into the fp32 C with
+// atomics.  C (fp32 [M, N], row stride ldc) is zeroed here; vt_residual_cast_bf16 turns it into bf16 (+ residual).
+// splits must divide K / 64; splits <= 0 picks the largest divisor <= 8 that keeps >= 8 K-tiles per piece and does not
+// exceed one work item per CU.
+extern "C" int VT_CAT(vt_gemm_splitk_f32, VT_SUFFIX)(const void* A, int lda, const void* W, int ldw, float* C, int ldc,
+                                                      int M, int N, int K, int splits, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % GP_BK) != 0 || (N % 4) != 0) return VT_ERR_BAD_SHAPE;
+    if ((lda % 8) || (ldw % 8) || (ldc % 4) || lda < K || ldw < K || ldc < N) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)A) | ((uintptr_t)W) | ((uintptr_t)C)) & 15) return VT_ERR_BAD_ALIGN;
+    const int nk = K / GP_BK;
+    if (splits <= 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const int tiles = ((M + GP_BM - 1) / GP_BM) * ((N + GP_BN - 1) / GP_BN);
+        splits = 1;
+        for (int s = 2; s <= 8; ++s)
+            if (nk % s == 0 && nk / s >= 8 && tiles * s <= cus) splits = s;
+    }
+    if (splits > nk || (nk % splits) != 0) return VT_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C; p.bias = nullptr; p.R = nullptr; p.gate_txt = nullptr; p.gate_vid = nullptr;
+    p.C2 = nullptr; p.U = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.ldc2 = 0; p.ldu = 0;
+    p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = splits;
+    if (splits > 1 && hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st) != hipSuccess) return VT_ERR_LAUNCH;
+    return VT_CAT(launch_pc, VT_SUFFIX)<EPI_BIAS, true>(p, st);
 }

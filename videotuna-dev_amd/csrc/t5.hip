@@ -69,3 +69,35 @@ extern "C" int vt_gated_gelu_bf16(const void* u, long long ldu, void* y, long lo
                        (const bf16_t*)u, ldu, (bf16_t*)y, ldy, M, F);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
+
+// out[m, n] = bf16(acc[m, n] (+ R[m, n])): the finishing pass of vt_gemm_splitk_f32 (fp32 partial sums -> bf16, residual add)
+__global__ __launch_bounds__(256) void residual_cast_kernel(const float* acc, long long lda, const bf16_t* R, long long ldr, bf16_t* out,
+                                                            long long ldo, long long M, int N) {
+    const int nch = N >> 3;
+    const long long total = M * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch);
+        const f32x4 a0 = *(const f32x4*)(acc + m * lda + c * 8), a1 = *(const f32x4*)(acc + m * lda + c * 8 + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (R != nullptr) {
+            float r[8];
+            unpack8(*(const u32x4*)(R + m * ldr + c * 8), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+        }
+        *(u32x4*)(out + m * ldo + c * 8) = pack8(v);
+    }
+}
+
+extern "C" int vt_residual_cast_bf16(const float* acc, long long lda, const void* R, long long ldr, void* out, long long ldo, long long M,
+                                     int N, void* stream) {
+    if (M <= 0 || N <= 0 || (N % 8) || (lda % 4) || (ldo % 8) || lda < N || ldo < N || (R != nullptr && ((ldr % 8) || ldr < N)))
+        return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)acc) | ((uintptr_t)out) | ((uintptr_t)R)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long total = M * (N >> 3);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(residual_cast_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, acc, lda,
+                       (const bf16_t*)R, ldr, (bf16_t*)out, ldo, M, N);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -190,6 +190,22 @@ def attn_fwd_bias(q, k, v, bias_t, o, lse2, B: int, H: int, S: int, scale: float
           "vt_attn_fwd_bias_hd64")
 
 
+def gemm_splitk(a, w, acc, splits: int = 0):
+    """acc[M,N] (fp32, overwritten) = a[M,K] @ w[N,K]^T with the K range split over the chip (few rows, large weight)"""
+    _req(a, BF16, "a", 2); _req(w, BF16, "w", 2); _req(acc, torch.float32, "acc", 2)
+    check(load_library().vt_gemm_splitk_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), acc.data_ptr(), acc.stride(0),
+                                            a.shape[0], w.shape[0], a.shape[1], splits, _stream()), "vt_gemm_splitk_f32")
+
+
+def residual_cast(acc, residual, out):
+    """out = bf16(acc + residual) (residual may be None)"""
+    _req(acc, torch.float32, "acc", 2); _req(out, BF16, "out", 2)
+    if residual is not None:
+        _req(residual, BF16, "residual", 2)
+    check(load_library().vt_residual_cast_bf16(acc.data_ptr(), acc.stride(0), _p(residual), 0 if residual is None else residual.stride(0),
+                                               out.data_ptr(), out.stride(0), acc.shape[0], acc.shape[1], _stream()), "vt_residual_cast_bf16")
+
+
 def rmsnorm(x, w, y, eps: float = 1e-6):
     """T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w (rows of a 2-d bf16 tensor)"""
     _req(x, BF16, "x", 2); _req(y, BF16, "y", 2); _req(w, BF16, "w", 1)

@@ -8,8 +8,8 @@ no attention mask) and by ``FrozenT5Embedder`` (videotuna/models/lvdm/modules/en
 real checkpoint loads with ``load_state_dict`` / ``from_pretrained``; forward only (the encoder is frozen).
 
 Per layer: vt_rmsnorm_bf16 -> one fused QKV GEMM -> vt_attn_fwd_bias_hd64 (unscaled scores + the bucketed relative position
-bias, shared by all layers) -> output GEMM with the residual add in its epilogue -> vt_rmsnorm_bf16 -> one fused wi_0|wi_1 GEMM
--> vt_gated_gelu_bf16 -> wo GEMM with the residual add in its epilogue.  At 226 tokens per prompt the encoder is bound by
+bias, shared by all layers) -> output GEMM with the residual add in its epilogue -> vt_rmsnorm_bf16 -> one fused wi_0|wi_1 GEMM -> vt_gated_gelu_bf16 ->
+wo GEMM with the residual add in its epilogue (option use_splitk: the two narrow GEMMs as vt_gemm_splitk_f32 + vt_residual_cast_bf16).  At 226 tokens per prompt the encoder is bound by
 streaming its weights once per batch (9.4 GB for T5-XXL).
 """
 from __future__ import annotations
@@ -132,6 +132,7 @@ class T5EncoderModel(nn.Module):
         self._bias_cache = {}
         self._graphs = {}
         self.use_graph = True
+        self.use_splitk = False        # measured slower than the plain producer / consumer GEMM at 2 x 226 tokens (11.2 vs 10.0 ms)
 
     # ------------------------------------------------------------------ weights
     @classmethod
@@ -248,6 +249,10 @@ class T5EncoderModel(nn.Module):
         h = torch.nn.functional.embedding(ids.reshape(-1), self.shared.weight)          # gather (plumbing): [M, d]
         x, qkv, o, u, g = E(M, d), E(M, 3 * inner), E(M, inner), E(M, 2 * F), E(M, F)
         lse = E(B, H, S, dt=torch.float32)
+        # option (use_splitk): the two GEMMs with only d / 128 column tiles run split-K over the chip (fp32 partial sums, residual
+        # added by the finishing pass).  Off by default: at M = 452 the extra epilogues and atomics cost more than the idle CUs.
+        splitk = M <= 1024 and self.use_splitk
+        acc = E(M, d, dt=torch.float32) if splitk else None
         qkv3, o3 = qkv.view(B, S, 3 * inner), o.view(B, S, inner)
         for blk, w_qkv, w_i in zip(self.encoder.block, wqkv, wi):
             at, ff = blk.layer[0], blk.layer[1]
@@ -255,12 +260,20 @@ class T5EncoderModel(nn.Module):
             ops.gemm(x, w_qkv, qkv)
             ops.attn_fwd_bias(qkv3[:, :, :inner], qkv3[:, :, inner:2 * inner], qkv3[:, :, 2 * inner:], bias_t, o3, lse, B, H, S, 1.0)
             h1 = E(M, d)
-            ops.gemm(o, at.SelfAttention.o.weight, h1, None, epilogue=EPI_GATED_RES, residual=h)
+            if splitk:
+                ops.gemm_splitk(o, at.SelfAttention.o.weight, acc)
+                ops.residual_cast(acc, h, h1)
+            else:
+                ops.gemm(o, at.SelfAttention.o.weight, h1, None, epilogue=EPI_GATED_RES, residual=h)
             ops.rmsnorm(h1, ff.layer_norm.weight, x, c.layer_norm_epsilon)
             ops.gemm(x, w_i, u)
             ops.gated_gelu(u, g)
             h = E(M, d)
-            ops.gemm(g, ff.DenseReluDense.wo.weight, h, None, epilogue=EPI_GATED_RES, residual=h1)
+            if splitk:
+                ops.gemm_splitk(g, ff.DenseReluDense.wo.weight, acc)
+                ops.residual_cast(acc, h1, h)
+            else:
+                ops.gemm(g, ff.DenseReluDense.wo.weight, h, None, epilogue=EPI_GATED_RES, residual=h1)
         out = E(M, d)
         ops.rmsnorm(h, self.encoder.final_layer_norm.weight, out, c.layer_norm_epsilon)
         return EncoderOutput((out.view(B, S, d),))

@@ -79,6 +79,9 @@
 #ifndef VT_CHAIN
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
+#ifndef VT_DQPRIO
+#define VT_DQPRIO 0   // 1 = waves 0..3 raise their issue priority for the dQ phase (s_setprio)
+#endif
 #ifndef VT_ABL
 #define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write, 5 = no row-constant reads, 6 = no transposed Q / dO reads, 7 = 5 + 6 (5..7: eight-wave body)
 #endif
@@ -465,6 +468,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #else
         // ---- dQ tile (32 q x 32 d) over all 256 keys: waves 0..3 only; waves 4..7 go on with the next step ----
         if (dqw) {
+#if VT_DQPRIO
+            __builtin_amdgcn_s_setprio(3);         // the step barrier waits for these waves: let them win the issue arbitration
+#endif
             if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);      // the barrier drained the memory pipeline
             const int s_cons = has_cons ? __builtin_amdgcn_readfirstlane(pf_cons) : 0;
             f32x16 dq_acc;
@@ -516,6 +522,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #endif
             }
             if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);
+#if VT_DQPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
 #endif

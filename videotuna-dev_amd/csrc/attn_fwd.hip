@@ -32,6 +32,9 @@ struct AttnFwdParams {
     const float* bias_t;   // BIAS kernels: additive score bias, TRANSPOSED [H][S keys][S queries] fp32 (same for every sample), or null
 };
 
+#ifndef VT_FWD_ABL
+#define VT_FWD_ABL 0     // timing-only ablations (results WRONG): 1 = K fragments read from one fixed LDS row set per step (no per-k-step reads), 2 = no V^T transposed reads, 3 = both
+#endif
 #ifndef VT_FWD_WAVES
 #define VT_FWD_WAVES 4  // waves per workgroup (32 queries each).  8 (256 queries share every K / V tile, half the staging per flop) measured
                         // within 1 % of 4 (2.447 vs 2.425 ms at B=1): staging is no longer what limits this kernel
@@ -179,7 +182,11 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int kt2 = 0; kt2 < 2; ++kt2) {
+#if VT_FWD_ABL & 1
+                    bf16x8 kf = qf[(s + kt2) & 3];
+#else
                     bf16x8 kf = *(const bf16x8*)(base + kt2 * 4096 + kfo[s]);
+#endif
                     st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? negm : st[kt2], 0, 0, 0);
                 }
             }
@@ -291,12 +298,16 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kt2][8 * s2 + j];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
+#if VT_FWD_ABL & 2
+                    o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(dt + s2 + kt2) & 3], pf, o_acc[dt], 0, 0, 0);
+#else
                     const char* vp = base + vfo[dt] + (kt2 * 32 + s2 * 16) * 128;
                     short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp));
                     short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp + 8 * 128));
                     typedef __attribute__((ext_vector_type(8))) short short8v;
                     short8v v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, o_acc[dt], 0, 0, 0);
+#endif
                 }
             }
         }

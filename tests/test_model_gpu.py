@@ -259,3 +259,67 @@ def test_t5_encoder_matches_oracle(dev, S):
     assert err < 3e-2, err
     cos = torch.nn.functional.cosine_similarity(out[0].double().cpu().reshape(-1), ref.reshape(-1), dim=0).item()
     assert cos > 0.9995, cos
+
+
+def test_lora_loss_curve_tracks_the_oracle_over_optimizer_steps(dev):
+    """North-star parity item "loss curve on fixed seeds": ten optimizer steps of the tiny LoRA recipe (two micro-batches per
+    step, AdamW with the reference's defaults, cogvideo_pl.py:774-779) on the device engine -- bf16 activations, fp32 master
+    weights, fused AdamW -- against the fp64 oracle trained with torch.optim.AdamW from the same initial adapters (the oracle
+    also forwards with the bf16-rounded copy of its master weights, as the device does).  The two loss curves must stay
+    together step by step, and training must actually reduce the loss."""
+    import cogvideox_oracle as O
+    from vt355.optim import FusedAdamW
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.selfcheck import build_tiny, oracle_params
+    from vt355.workflow import _LossFn
+    cfg, model, peft, st = build_tiny(dev)
+    Fr = (cfg.sample_frames - 1) // 4 + 1
+    sched = CogVideoXDPMScheduler()
+    abar = O.alphas_cumprod_cogvideox()
+    lr, steps, accum, B = 2e-2, 10, 2, 2
+
+    def batch(i):                    # two fixed micro-batches, revisited every step (a curve that can go down)
+        g = torch.Generator().manual_seed(1000 + i % accum)
+        x0 = torch.randn(B, Fr, 16, cfg.sample_height, cfg.sample_width, generator=g)
+        text = (torch.randn(B, cfg.max_text_seq_length, cfg.text_embed_dim, generator=g) * 0.5).to(torch.bfloat16)
+        noise = torch.randn(x0.shape, generator=g)
+        t = torch.tensor([150 + 40 * (i % accum), 700 - 60 * (i % accum)])
+        return x0, text, noise, t
+
+    P, _ = oracle_params(model, st, torch.float64)
+    names = []
+    for (layer, kind, j) in st._index:
+        names.append(f"transformer_blocks.{layer}.attn1.{('to_q', 'to_k', 'to_v', 'to_out.0')[j]}.lora_{kind}.default.weight")
+    master = [p.detach().double().cpu().clone().requires_grad_(True) for p in st.params]       # fp32 master values, exactly
+    opt_ref = torch.optim.AdamW(master, lr=lr)
+    opt_dev = FusedAdamW(st.params, lr=lr, lora_state=st)
+    curve_dev, curve_ref = [], []
+    for s in range(steps):
+        opt_dev.zero_grad(); opt_ref.zero_grad()
+        ld = lr_ = 0.0
+        for mb in range(accum):
+            x0, text, noise, t = batch(mb)
+            noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
+            out = peft(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev), return_dict=False)[0]
+            sa, sb, w = sched.coefficients(t.to(dev))
+            loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
+            (loss / accum).backward()
+            ld += loss.item() / accum
+            # oracle: forward with the bf16-rounded adapters (straight-through to the fp64 master)
+            Lo = {n: (m.detach().to(torch.bfloat16).double() - m.detach()) + m for n, m in zip(names, master)}
+            noisy_ref = noisy.float().cpu().double()
+            out_ref = O.dit_forward(P, cfg, noisy_ref, text.double(), t, Lo, st.scaling)
+            pred = O.get_velocity(out_ref, noisy_ref, t, abar)
+            wref = (1.0 / (1.0 - abar[t])).view(-1, 1, 1, 1, 1)
+            loss_ref = torch.mean((wref * (pred - x0.double()) ** 2).reshape(B, -1), dim=1).mean()
+            (loss_ref / accum).backward()
+            lr_ += loss_ref.item() / accum
+        opt_dev.step(); opt_ref.step()
+        curve_dev.append(ld); curve_ref.append(lr_)
+    print("loss curve dev", ["%.5f" % v for v in curve_dev]); print("loss curve ref", ["%.5f" % v for v in curve_ref])
+    for a, b in zip(curve_dev, curve_ref):
+        assert abs(a - b) / b < 1e-3, (curve_dev, curve_ref)          # north_star: "loss curve within 1e-3 ... on fixed seeds"
+    assert curve_ref[-1] < 0.99 * curve_ref[0] and curve_dev[-1] < 0.99 * curve_dev[0], (curve_dev, curve_ref)
+    drift = torch.cat([p.detach().double().cpu().reshape(-1) - m.detach().reshape(-1) for p, m in zip(st.params, master)])
+    moved = torch.cat([m.detach().reshape(-1) for m in master]).norm().item()
+    assert drift.norm().item() < 0.1 * moved, (drift.norm().item(), moved)

@@ -248,6 +248,7 @@ def main():
                        "weights": "seeded random init (no checkpoints offline)",
                        "text": ("T5-XXL encoder (vt355.t5, random weights) in the loop, one step ahead on a side stream"
                                 if args.text_encoder else "pre-encoded prompt embeddings (synthetic)")},
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,
                          "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_summary.json; "

@@ -24,12 +24,19 @@
 #define VT_CAT(a, b) VT_CAT_(a, b)
 #define GEMM_PC_KERNEL VT_CAT(gemm_tn_pc_kernel, VT_SUFFIX)
 
-#define GP_BM 256
+#define GP_BM 256           // rows of the standard tile; the BM = 128 instantiation (four-stage ring) serves few-row GEMMs
 #define GP_BN 128
 #define GP_BK 64
-#define GP_STAGE 49152      // A 32 KiB | W 16 KiB
-#define GP_NS 3
 #define GP_CS_LD 132        // fp32 row stride of the epilogue staging slab (32 rows x 132 floats = 16.5 KiB)
+template <int BM> struct GpCfg {
+    static constexpr int STAGE = BM * 128 + 16384;          // A (BM rows x 128 B) | W 16 KiB
+    static constexpr int NS = BM == 256 ? 3 : 4;            // ring stages: 144 KiB / 128 KiB of LDS
+    static constexpr int AHEAD = NS - 1;                    // K-tiles the loaders run ahead of the multipliers
+    static constexpr int APIECES = BM / 32;                 // 1-KiB pieces of A per loader wave per K-tile
+    static constexpr int PIECES = APIECES + 4;              // ... plus 4 of W
+    static constexpr int SLABS = BM / 32;                   // 32-row epilogue slabs
+    static constexpr int TM = BM / 64;                      // 32-row A fragments per multiplier wave
+};
 
 static __device__ __forceinline__ void gp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -40,6 +47,7 @@ struct GpTile {
     unsigned a_bytes, w_bytes;
 };
 
+template <int BM>
 static __device__ __forceinline__ GpTile gp_tile(const GemmParams& p, int id, int nbm, int nbn) {
     // grouped ordering (4 row-tiles per group, column-tiles outer): the 32 workgroups of an XCD that run together share
     // A row-panels / W column-panels in its L2
@@ -49,7 +57,7 @@ static __device__ __forceinline__ GpTile gp_tile(const GemmParams& p, int id, in
     const int first_m = group * GM;
     const int gsz = min(nbm - first_m, GM);
     GpTile t;
-    t.row0 = (first_m + (id % in_group) % gsz) * GP_BM;
+    t.row0 = (first_m + (id % in_group) % gsz) * BM;
     t.col0 = ((id % in_group) / gsz) * GP_BN;
     const long long a_rem = (long long)(p.M - t.row0) * p.lda * 2;
     const long long w_rem = (long long)(p.N - t.col0) * p.ldw * 2;
@@ -60,13 +68,15 @@ static __device__ __forceinline__ GpTile gp_tile(const GemmParams& p, int id, in
     return t;
 }
 
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, int BM>
 __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
+    using Cfg = GpCfg<BM>;
+    constexpr int GP_STAGE = Cfg::STAGE, GP_NS = Cfg::NS;
     __shared__ __attribute__((aligned(16))) char smem[GP_NS * GP_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
-    const int nbm = (p.M + GP_BM - 1) / GP_BM, nbn = (p.N + GP_BN - 1) / GP_BN;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + GP_BN - 1) / GP_BN;
     // split-K (p.splits > 1, fp32 C, EPI_BIAS only; the host guarantees (K / 64) % splits == 0): a work item is (output tile,
     // K range); item w = tile w % ntiles_mn of split w / ntiles_mn, so the workgroups that run together share one K range of A
     const int ntiles_mn = nbm * nbn;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
         const int a_voff0 = row0p * p.lda * 2 + ((dcp ^ sw) << 4);
         const int w_voff0 = row0p * p.ldw * 2 + ((dcp ^ sw) << 4);
         const int a_pstep = 32 * p.lda * 2, w_pstep = 32 * p.ldw * 2;
-        GpTile cur = gp_tile(p, slot % ntiles_mn, nbm, nbn);
+        GpTile cur = gp_tile<BM>(p, slot % ntiles_mn, nbm, nbn);
         int tile = slot, kt = 0;
         int kbase = (slot / ntiles_mn) * nk;
         auto issue = [&](int g) {                // K-tile number g of the stream -> stage g % 3
@@ -99,37 +109,41 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
             const int soff = (kbase + kt) * GP_BK * 2;
             char* st = smem + (g % GP_NS) * GP_STAGE + lw * 1024;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < Cfg::APIECES; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + j * 4096), 16, a_voff0, soff + j * a_pstep, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 32768 + j * 4096), 16, w_voff0, soff + j * w_pstep, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + BM * 128 + j * 4096), 16, w_voff0, soff + j * w_pstep, 0, 0);
             if (++kt == nk) {                    // next K-tile belongs to the next output tile
                 kt = 0;
                 tile += gridDim.x;
-                if (tile < ntiles) { cur = gp_tile(p, tile % ntiles_mn, nbm, nbn); kbase = (tile / ntiles_mn) * nk; }
+                if (tile < ntiles) { cur = gp_tile<BM>(p, tile % ntiles_mn, nbm, nbn); kbase = (tile / ntiles_mn) * nk; }
             }
         };
         int issued = 0;
-        for (; issued < 2 && issued < total_kt; ++issued) issue(issued);
+        for (; issued < Cfg::AHEAD && issued < total_kt; ++issued) issue(issued);
         for (int g = 0; g < total_kt; ++g) {
-            // K-tile g must have landed before the barrier that hands it to the multipliers; K-tile g+1 may stay in flight
-            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            // K-tile g must have landed before the barrier that hands it to the multipliers; the younger ones may stay in flight
+            // (vmcnt retires in order: PIECES operations per K-tile and wave)
+            const int younger = issued - g - 1;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::PIECES) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PIECES) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            gp_barrier();                        // (A) stage g % 3 is ready / stage (g-1) % 3 has been consumed
+            gp_barrier();                        // (A) stage g % NS is ready / stage (g-1) % NS has been consumed
             const bool tile_end = (g + 1) % nk == 0;
             if (tile_end) {
-                // the multipliers stage their accumulators through stage g % 3 ... (g+2) % 3 are not touched; mirror their barriers
+                // the multipliers stage their accumulators through stage g % NS, the stages in flight are not touched; mirror their barriers
 #pragma unroll 1
-                for (int i = 0; i < 17; ++i) gp_barrier();
+                for (int i = 0; i < 1 + 2 * Cfg::SLABS; ++i) gp_barrier();
             }
-            if (issued < total_kt) { issue(issued); ++issued; }      // into stage (g+2) % 3 = (g-1) % 3: consumed before barrier (A)
+            if (issued < total_kt) { issue(issued); ++issued; }      // into stage (g+AHEAD) % NS = (g-1) % NS: consumed before barrier (A)
         }
         return;
     }
 
     // =================================== multiplier waves ===================================
-    const int wm = wave & 1, wn = wave >> 1;                  // 2 x 2 waves: rows 128 wm .., columns 64 wn ..
+    constexpr int TM = Cfg::TM;
+    const int wm = wave & 1, wn = wave >> 1;                  // 2 x 2 waves: rows (BM/2) wm .., columns 64 wn ..
     const int fr = lane & 31;             // row inside a 32-row fragment
     const int fh = lane >> 5;             // which 8-element half of a 16-deep k-step
     const int fx = (fr >> 1) & 7;         // swz(row)
@@ -137,26 +151,26 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
     const int ec = (tid & 31) * 4;        // first of this thread's 4 columns
     int g = 0;
     for (int tile = slot; tile < ntiles; tile += gridDim.x) {
-        const GpTile cur = gp_tile(p, tile % ntiles_mn, nbm, nbn);
+        const GpTile cur = gp_tile<BM>(p, tile % ntiles_mn, nbm, nbn);
         // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
         // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
-        f32x16 acc[2][4];
+        f32x16 acc[2][TM];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         for (int kt = 0; kt < nk; ++kt, ++g) {
             gp_barrier();                    // (A) the loaders have landed stage g % 3
-            const char* As = smem + (g % GP_NS) * GP_STAGE + (wm * 128 + fr) * 128;
-            const char* Ws = smem + (g % GP_NS) * GP_STAGE + 32768 + (wn * 64 + fr) * 128;
-            bf16x8 af[2][4], wf[2][2];       // fragments of k-step ks in [ks & 1]: the next ones load under the current MFMAs
+            const char* As = smem + (g % GP_NS) * GP_STAGE + (wm * (BM / 2) + fr) * 128;
+            const char* Ws = smem + (g % GP_NS) * GP_STAGE + BM * 128 + (wn * 64 + fr) * 128;
+            bf16x8 af[2][TM], wf[2][2];      // fragments of k-step ks in [ks & 1]: the next ones load under the current MFMAs
             auto frags = [&](int ks) {
                 const int coff = (((ks * 2 + fh) ^ fx) << 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) af[ks & 1][t] = *(const bf16x8*)(As + t * 4096 + coff);
+                for (int t = 0; t < TM; ++t) af[ks & 1][t] = *(const bf16x8*)(As + t * 4096 + coff);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) wf[ks & 1][t] = *(const bf16x8*)(Ws + t * 4096 + coff);
             };
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                 // them to just before their use and a lone wave then waits out the LDS latency twice per k-step)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn)
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][tn], af[ks & 1][tm], acc[tn][tm], 0, 0, 0);
@@ -196,12 +210,12 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
         };
         aux_fetch(0, aux);
         GateCtx gctx;
-        if (EPI == EPI_GATED_RES) gctx = gate_ctx_load(p, cur.row0, GP_BM, n);
+        if (EPI == EPI_GATED_RES) gctx = gate_ctx_load(p, cur.row0, BM, n);
         gp_barrier();                        // every multiplier is done reading the stage (the loaders mirror this one too)
 #pragma unroll
-        for (int slab = 0; slab < 8; ++slab) {
-            if (wm == (slab >> 2)) {
-                const int tm = slab & 3;
+        for (int slab = 0; slab < Cfg::SLABS; ++slab) {
+            if (wm == slab / TM) {
+                const int tm = slab % TM;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                     }
             }
             gp_barrier();
-            if (slab < 7) aux_fetch(slab + 1, auxn);
+            if (slab < Cfg::SLABS - 1) aux_fetch(slab + 1, auxn);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int ml = pass * 8 + er;
@@ -229,9 +243,14 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
     }
 }
 
+// BM = 128 (four-stage ring, three K-tiles in flight) for GEMMs with few rows: twice the workgroups on the narrow outputs
+static bool VT_CAT(pc_small_m, VT_SUFFIX)(const GemmParams& p) { return p.M <= 1024; }
+
 template <int EPI, bool F32>
 static int VT_CAT(launch_pc, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
-    const int nbm = (p.M + GP_BM - 1) / GP_BM, nbn = (p.N + GP_BN - 1) / GP_BN;
+    const bool small = VT_CAT(pc_small_m, VT_SUFFIX)(p);
+    const int bm = small ? 128 : GP_BM;
+    const int nbm = (p.M + bm - 1) / bm, nbn = (p.N + GP_BN - 1) / GP_BN;
     static int slots = 0;                 // persistent grid: one workgroup per CU, a multiple of 8
     if (slots == 0) {
         int dev = 0, cus = 0;
@@ -240,7 +259,8 @@ static int VT_CAT(launch_pc, VT_SUFFIX)(const GemmParams& p, hipStream_t st) {
     }
     const int ntiles = nbm * nbn * (p.splits > 1 ? p.splits : 1);
     const int grid = ntiles < slots ? (ntiles + 7) / 8 * 8 : slots;
-    hipLaunchKernelGGL((GEMM_PC_KERNEL<EPI, F32>), dim3(grid), dim3(512), 0, st, p);
+    if (small) hipLaunchKernelGGL((GEMM_PC_KERNEL<EPI, F32, 128>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((GEMM_PC_KERNEL<EPI, F32, GP_BM>), dim3(grid), dim3(512), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 

@@ -12,6 +12,8 @@ hipcc $F -DVT_W8=0 -DVT_SUFFIX=_w4 -mllvm -amdgpu-sched-strategy=max-ilp -c "$HE
 hipcc $F -DVT_DQ16=1 -DVT_SUFFIX=_dq16 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_dq16.o" &
 hipcc $F -DVT_SUFFIX=_same -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_same.o" &
 hipcc $F -DVT_SUFFIX=_prio -DVT_DQPRIO=1 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_prio.o" &
+hipcc $F -DVT_SUFFIX=_ant -DVT_ATOM_AUX=2 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_ant.o" &
+hipcc $F -DVT_SUFFIX=_asc1 -DVT_ATOM_AUX=16 -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_asc1.o" &
 # timing-only ablations of the eight-wave body (wrong results): which resource the step is bound by
 for a in 1 2 5 6 7; do
   hipcc $F -DVT_SUFFIX=_abl$a -DVT_ABL=$a -c "$HERE/attn_bwd.hip" -o "$HERE/obj_exp/bwd_abl$a.o" &

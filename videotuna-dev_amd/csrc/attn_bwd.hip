@@ -79,6 +79,9 @@
 #ifndef VT_CHAIN
 #define VT_CHAIN 1    // 0 = compile the dQ hand-off chains out (persistent scheduling only)
 #endif
+#ifndef VT_ATOM_AUX
+#define VT_ATOM_AUX 0  // cache-policy bits of the dQ atomics of the eight-wave body (2 = nt, 16 = sc1): measured, no effect
+#endif
 #ifndef VT_DQPRIO
 #define VT_DQPRIO 0   // 1 = waves 0..3 raise their issue priority for the dQ phase (s_setprio)
 #endif
@@ -518,7 +521,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff,
-                                                                    soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
+                                                                    soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, VT_ATOM_AUX);
 #endif
             }
             if (has_prod) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t + 1), rfl, fl_cons_me, 0, CH_AUX);

@@ -108,6 +108,15 @@ int vt_attn_fwd_bias_hd64(const void* q, const void* k, const void* v, const flo
 int vt_gemm_splitk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int splits, void* stream);
 int vt_residual_cast_bf16(const float* acc, long long lda, const void* R, long long ldr, void* out, long long ldo, long long M, int N,
                           void* stream);
+/* GroupNorm (+ SiLU) over channels-last activations: x, y bf16 [N, P, C] (P = T*H*W positions, position stride ldx / ldy), G groups
+ * of C/G channels, statistics over (P x C/G) in fp32, y = silu?((x - mean) * rstd * gamma + beta).  ws: fp32 scratch of
+ * vt_groupnorm_ws_bytes(N, C) bytes.  First kernel of the next scope rows: replaces `Normalize` -> `nonlinearity` in
+ * the CogVideoX VAE's ResNet blocks (cogvideo_sat/vae_modules/cp_enc_dec.py:436-459, 681-777; diffusers AutoencoderKLCogVideoX
+ * behind cogvideo_pl.py:792-813) and GroupNorm32 -> SiLU in the VideoCrafter2 UNet (lvdm/modules/networks/openaimodel3d.py:229-255),
+ * on one channels-last layout instead of the reference's NCHW <-> NCTHW permutes. */
+long long vt_groupnorm_ws_bytes(int N, int C);
+int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* gamma, const void* beta, void* y, long long ldy,
+                         int N, long long P, int C, int G, float eps, int silu, float* ws, long long ws_bytes, void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);

@@ -506,3 +506,27 @@ def test_gemm_splitk_and_residual_cast(dev, M, N, K, splits):
     close(out, ref, 1e-2, 1e-2 * ref.abs().max().item(), "cast")
     with pytest.raises(VtError, match="vt_gemm_splitk_f32"):         # splits must divide K / 64
         ops.gemm_splitk(a.to(dev, BF)[:, :K], w.to(dev, BF), acc, 7 if (K // 64) % 7 else 9)
+
+
+# ------------------------------------------------------------------ GroupNorm + SiLU, channels-last (first kernel of the VAE / UNet rows)
+@pytest.mark.parametrize("N,P,C,G,silu", [(2, 1000, 128, 32, True), (1, 777, 320, 32, True), (3, 64, 512, 32, False),
+                                          (1, 13 * 60 * 90, 256, 32, True), (2, 5, 64, 8, True)])
+def test_groupnorm_silu_channels_last(dev, N, P, C, G, silu):
+    """F.silu(F.group_norm(x, G, gamma, beta, eps)) on [N, C, P] in fp32 vs the channels-last kernel on [N, P, C] bf16
+    (10 channels per group at C = 320 like the UNet, 4 at C = 128 like the VAE's first block; strided positions)"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(P + C)
+    xb = rb(torch.randn(N, P, C + 8, generator=g) * 1.7 + 0.6)
+    gamma = rb(1.0 + 0.3 * torch.randn(C, generator=g)); beta = rb(0.2 * torch.randn(C, generator=g))
+    x = xb[:, :, :C]
+    ref = F.group_norm(x.transpose(1, 2).contiguous(), G, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.transpose(1, 2)
+    X = xb.to(dev, BF)
+    y = torch.full((N, P, C + 16), 5.0, dtype=BF, device=dev)
+    ops.groupnorm_silu(X[:, :, :C], gamma.to(dev, BF), beta.to(dev, BF), y[:, :, :C], G, 1e-6, silu)
+    close(y[:, :, :C], ref, 1e-2, 1.5e-2, "groupnorm+silu"); assert (y[:, :, C:] == 5).all()
+    y2 = torch.empty(N, P, C, dtype=BF, device=dev)
+    ops.groupnorm_silu(X[:, :, :C], None, None, y2, G, 1e-6, False)
+    close(y2, F.group_norm(x.transpose(1, 2).contiguous(), G, None, None, 1e-6).transpose(1, 2), 1e-2, 1.5e-2, "groupnorm, no affine")

@@ -156,6 +156,14 @@ def main():
             print(f"   transformers T5EncoderModel bf16 (eager, rocBLAS/hipBLASLt): {med2:.2f} ms", flush=True)
         except Exception as e:
             print("   transformers calibration unavailable:", repr(e)[:200], flush=True)
+    if "gn" in which:         # GroupNorm + SiLU, channels-last, at the VAE encoder's block sizes (49x480x720 input): 6 bytes per element
+        for (P, C, name) in [(13 * 480 * 720, 128, "block0 (quarter of the 49 frames)"), (25 * 240 * 360, 256, "block1"), (13 * 120 * 180, 256, "block2"),
+                             (13 * 60 * 90, 512, "block3 / mid")]:
+            x = torch.randn(1, P, C, device=dev).to(BF); y = torch.empty_like(x)
+            ga = torch.ones(C, dtype=BF, device=dev); be = torch.zeros(C, dtype=BF, device=dev)
+            ws = torch.empty(4 * C, device=dev)
+            med, mn = timeit(lambda: ops.groupnorm_silu(x, ga, be, y, 32, 1e-6, True, ws))
+            print(f"groupnorm+silu {name}: P={P} C={C}: {med*1e3:.1f} us  {6.0*P*C/med/1e6:.0f} GB/s", flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

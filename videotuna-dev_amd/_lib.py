@@ -37,6 +37,8 @@ PROTOTYPES = {
     "vt_attn_fwd_bias_hd64": [_vp, _vp, _vp, _fp, _vp, _fp, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp],
     "vt_gemm_splitk_f32": [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _i, _vp],
     "vt_residual_cast_bf16": [_fp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _vp],
+    "vt_groupnorm_ws_bytes": [_i, _i],
+    "vt_groupnorm_silu_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _ll, _i, _i, _f, _i, _fp, _ll, _vp],
     "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],
     "vt_gated_gelu_bf16": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
@@ -65,7 +67,7 @@ PROTOTYPES = {
     "vt_lora_pack_bt": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
 }
 _RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p, "vt_skinny_tn_workspace_bytes": C.c_longlong,
-             "vt_attn_bwd_chain_ws_bytes": C.c_longlong}
+             "vt_attn_bwd_chain_ws_bytes": C.c_longlong, "vt_groupnorm_ws_bytes": C.c_longlong}
 
 
 def load_library():

@@ -1,0 +1,114 @@
+// GroupNorm (+ SiLU) over channels-last activations [N, P, C] (P = T*H*W positions), bf16 in / out, fp32 statistics.
+// First kernel of the next scope rows: the block `GroupNorm(32) -> SiLU -> conv` opens every ResNet block
+// of the CogVideoX 3D causal VAE encoder (the step before the DiT, cogvideo_pl.py:792-813 -> AutoencoderKLCogVideoX; SAT twin
+// videotuna/models/cogvideo_sat/vae_modules/cp_enc_dec.py:436-459, 681-777) and of the VideoCrafter2 UNet
+// (videotuna/models/lvdm/modules/networks/openaimodel3d.py:229-255, `normalization` = GroupNorm32 in lvdm/basics.py).
+// The reference keeps NCHW / NCTHW and permutes between 2-D and 3-D views; here the layout is channels-last once and for all,
+// which is also what an implicit-GEMM convolution wants for its K dimension.
+//
+// HBM-bound: x is read twice (statistics, apply) and y written once = 6 bytes per element.  Three launches:
+//   1. per-CHANNEL sums and sums of squares: a thread owns 8 consecutive channels and strides over the positions, block reduction
+//      through LDS, one fp32 atomic per channel and block into ws (any channels-per-group works, e.g. 320 / 32 = 10);
+//   2. fold channels into groups -> per-channel affine  y = x * a[n,c] + b[n,c]  (a = rstd*gamma, b = beta - mean*rstd*gamma);
+//   3. apply (+ SiLU).
+#include "common.h"
+
+#define GN_THREADS 256
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* x, long long ldx, long long P, int C, float* ws,
+                                                              int slabs) {
+    extern __shared__ float red[];                 // [2][C]
+    const int n = blockIdx.y, slab = blockIdx.x;
+    const int nch = C >> 3;                        // 16-byte chunks per position
+    const int lanes = GN_THREADS / nch * nch;      // threads that take part (a whole number of positions per pass)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += GN_THREADS) red[i] = 0.f;
+    __syncthreads();
+    const long long p0 = P * slab / slabs, p1 = P * (slab + 1) / slabs;
+    if (tid < lanes) {
+        const int c = tid % nch, row = tid / nch, rows = lanes / nch;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        const bf16_t* xb = x + ((long long)n * P) * ldx + c * 8;
+        for (long long p = p0 + row; p < p1; p += rows) {
+            float v[8];
+            unpack8(*(const u32x4*)(xb + p * ldx), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(red + c * 8 + j, s[j]); atomicAdd(red + C + c * 8 + j, q[j]); }
+    }
+    __syncthreads();
+    float* w = ws + (size_t)n * 4 * C;
+    for (int i = tid; i < 2 * C; i += GN_THREADS) atomicAdd(w + i, red[i]);
+}
+
+__global__ void gn_finalize_kernel(float* ws, const bf16_t* gamma, const bf16_t* beta, long long P, int C, int G, float eps) {
+    const int n = blockIdx.x;
+    float* w = ws + (size_t)n * 4 * C;
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float s = 0.f, q = 0.f;
+        for (int j = 0; j < cpg; ++j) { s += w[g * cpg + j]; q += w[C + g * cpg + j]; }
+        const float cnt = (float)cpg * (float)P;
+        const float mean = s / cnt;
+        const float var = fmaxf(q / cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        for (int j = 0; j < cpg; ++j) {
+            const int c = g * cpg + j;
+            const float ga = gamma ? bf2f(gamma[c]) : 1.f, be = beta ? bf2f(beta[c]) : 0.f;
+            w[2 * C + c] = rstd * ga;
+            w[3 * C + c] = be - mean * rstd * ga;
+        }
+    }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* x, long long ldx, bf16_t* y, long long ldy, long long P, int C,
+                                                              const float* ws) {
+    const int n = blockIdx.y;
+    const int nch = C >> 3;
+    const float* a = ws + (size_t)n * 4 * C + 2 * C;
+    const float* b = a + C;
+    const long long total = P * nch;
+    for (long long i = (long long)blockIdx.x * GN_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * GN_THREADS) {
+        const long long p = i / nch;
+        const int c = (int)(i - p * nch) * 8;
+        float v[8];
+        unpack8(*(const u32x4*)(x + ((long long)n * P + p) * ldx + c), v);
+        const f32x4 a0 = *(const f32x4*)(a + c), a1 = *(const f32x4*)(a + c + 4), b0 = *(const f32x4*)(b + c), b1 = *(const f32x4*)(b + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = v[j] * a0[j] + b0[j]; v[j + 4] = v[j + 4] * a1[j] + b1[j]; }
+        if (SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * (1.0f - __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v[j] * 1.4426950408889634f) + 1.0f));
+        }
+        *(u32x4*)(y + ((long long)n * P + p) * ldy + c) = pack8(v);
+    }
+}
+
+extern "C" long long vt_groupnorm_ws_bytes(int N, int C) { return (long long)N * 4 * C * 4; }
+
+// x, y: [N, P, C] bf16 with position stride ldx / ldy (>= C, multiples of 8); gamma / beta: bf16 [C] or null; ws: fp32 scratch of
+// vt_groupnorm_ws_bytes(N, C) bytes (contents don't matter).  silu != 0 applies x*sigmoid(x) to the normalised value.
+extern "C" int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* gamma, const void* beta, void* y, long long ldy,
+                                    int N, long long P, int C, int G, float eps, int silu, float* ws, long long ws_bytes, void* stream) {
+    if (N <= 0 || P <= 0 || C <= 0 || G <= 0 || (C % G) || (C % 8) || C > 8 * GN_THREADS || (ldx % 8) || (ldy % 8) || ldx < C || ldy < C)
+        return VT_ERR_BAD_SHAPE;
+    if (N > 65535 || ws == nullptr || ws_bytes < vt_groupnorm_ws_bytes(N, C)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return VT_ERR_BAD_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, (size_t)N * 4 * C * 4, st) != hipSuccess) return VT_ERR_LAUNCH;
+    long long want = (P * N + 255) / 256 / N;        // >= ~256 positions per block, at most 2048 blocks per sample (8 per CU)
+    int slabs = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, N), dim3(GN_THREADS), 2 * C * sizeof(float), st, (const bf16_t*)x, ldx, P, C, ws, slabs);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(64), 0, st, ws, (const bf16_t*)gamma, (const bf16_t*)beta, P, C, G, eps);
+    const long long total = P * (C >> 3);
+    long long blocks = (total + GN_THREADS - 1) / GN_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)blocks, N), dim3(GN_THREADS), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, P, C, ws);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)blocks, N), dim3(GN_THREADS), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, P, C, ws);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

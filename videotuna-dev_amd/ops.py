@@ -206,6 +206,21 @@ def residual_cast(acc, residual, out):
                                                out.data_ptr(), out.stride(0), acc.shape[0], acc.shape[1], _stream()), "vt_residual_cast_bf16")
 
 
+def groupnorm_silu(x, gamma, beta, y, groups: int = 32, eps: float = 1e-6, silu: bool = True, ws: Optional[torch.Tensor] = None):
+    """channels-last GroupNorm (+ SiLU): x, y bf16 [N, P, C] (position stride = stride(1)); gamma / beta bf16 [C] or None"""
+    _req(x, BF16, "x", 3); _req(y, BF16, "y", 3)
+    N, P, C = x.shape
+    if x.stride(0) != P * x.stride(1) or y.stride(0) != P * y.stride(1):
+        raise ValueError("x / y: samples must be P positions apart")
+    lib = load_library()
+    need = int(lib.vt_groupnorm_ws_bytes(N, C))
+    if ws is None:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    check(lib.vt_groupnorm_silu_cl(x.data_ptr(), x.stride(1), _p(gamma), _p(beta), y.data_ptr(), y.stride(1), N, P, C, groups, eps,
+                                   int(silu), ws.data_ptr(), ws.numel() * 4, _stream()), "vt_groupnorm_silu_cl")
+    return y
+
+
 def rmsnorm(x, w, y, eps: float = 1e-6):
     """T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w (rows of a 2-d bf16 tensor)"""
     _req(x, BF16, "x", 2); _req(y, BF16, "y", 2); _req(w, BF16, "w", 1)

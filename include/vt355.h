@@ -117,6 +117,14 @@ int vt_residual_cast_bf16(const float* acc, long long lda, const void* R, long l
 long long vt_groupnorm_ws_bytes(int N, int C);
 int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* gamma, const void* beta, void* y, long long ldy,
                          int N, long long P, int C, int G, float eps, int silu, float* ws, long long ws_bytes, void* stream);
+/* Causal 3x3x3 convolution on channels-last video activations as an implicit GEMM (no im2col buffer):
+ *   y[n,t,h,w,co] = bias[co] + sum_{dt,dh,dw} sum_ci x[n, max(t+dt-2,0), h+dh-1, w+dw-1, ci] * wk[co, (dt,dh,dw), ci]
+ * zero padding in h / w, the first frame replicated in front of t.  x: bf16 [N,T,H,W,Cin] (position stride ldx), wk: bf16
+ * [Cout, 27*Cin] = torch's Conv3d weight permuted to [Cout,3,3,3,Cin], bias bf16 [Cout] or NULL, y: bf16 [N,T,H,W,Cout].
+ * Cin % 64 == 0, Cout % 4 == 0.  Replaces: ContextParallelCausalConv3d (cogvideo_sat/vae_modules/cp_enc_dec.py:356-433) /
+ * diffusers CogVideoXCausalConv3d in the VAE encoder the reference runs at cogvideo_pl.py:792-813. */
+int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
+                        int N, int T, int H, int W, int Cin, int Cout, void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);

@@ -530,3 +530,25 @@ def test_groupnorm_silu_channels_last(dev, N, P, C, G, silu):
     y2 = torch.empty(N, P, C, dtype=BF, device=dev)
     ops.groupnorm_silu(X[:, :, :C], None, None, y2, G, 1e-6, False)
     close(y2, F.group_norm(x.transpose(1, 2).contiguous(), G, None, None, 1e-6).transpose(1, 2), 1e-2, 1.5e-2, "groupnorm, no affine")
+
+
+@pytest.mark.parametrize("N,T,H,W,Cin,Cout", [(1, 3, 5, 7, 64, 64), (2, 4, 9, 10, 128, 256), (1, 1, 16, 12, 64, 132), (1, 5, 20, 33, 256, 128)])
+def test_causal_conv3d_channels_last(dev, N, T, H, W, Cin, Cout):
+    """implicit-GEMM causal conv3d vs fp32 F.conv3d on the causally padded input (first frame replicated twice in front of t,
+    zeros around h / w) -- the padding of the CogVideoX VAE's causal convolutions; tiles that straddle samples, ragged M,
+    a single frame, channel-sliced (strided) input and output"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(T * H * W + Cin)
+    xb = rb(torch.randn(N, T, H, W, Cin + 8, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (1.0 / (27 * Cin) ** 0.5)); b = rb(torch.randn(Cout, generator=g))
+    x = xb[..., :Cin]
+    xin = x.permute(0, 4, 1, 2, 3)
+    xpad = torch.cat([xin[:, :, :1]] * 2 + [xin], dim=2)
+    ref = F.conv3d(xpad, w, b, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+    X = xb.to(dev, BF)
+    y = torch.full((N, T, H, W, Cout + 4), 3.0, dtype=BF, device=dev)
+    ops.causal_conv3d(X[..., :Cin], ops.pack_conv3d_weight(w).to(dev, BF), b.to(dev, BF), y[..., :Cout])
+    close(y[..., :Cout], ref, 1e-2, 1e-2 * ref.abs().max().item(), "causal conv3d"); assert (y[..., Cout:] == 3).all()
+    y2 = torch.empty(N, T, H, W, Cout, dtype=BF, device=dev)
+    ops.causal_conv3d(X[..., :Cin], ops.pack_conv3d_weight(w).to(dev, BF), None, y2)
+    close(y2, ref - b, 1e-2, 1e-2 * ref.abs().max().item(), "causal conv3d, no bias")

@@ -164,6 +164,14 @@ def main():
             ws = torch.empty(4 * C, device=dev)
             med, mn = timeit(lambda: ops.groupnorm_silu(x, ga, be, y, 32, 1e-6, True, ws))
             print(f"groupnorm+silu {name}: P={P} C={C}: {med*1e3:.1f} us  {6.0*P*C/med/1e6:.0f} GB/s", flush=True)
+    if "conv" in which:       # causal 3x3x3 convolution (implicit GEMM) at the CogVideoX VAE encoder's block sizes
+        for (T_, H_, W_, Ci, Co, name) in [(4, 480, 720, 128, 128, "block0 (4 of 49 frames)"), (13, 240, 360, 256, 256, "block1 (13 of 25 frames)"),
+                                           (13, 120, 180, 256, 256, "block2"), (13, 60, 90, 512, 512, "block3 / mid")]:
+            x = torch.randn(1, T_, H_, W_, Ci, device=dev).to(BF); y = torch.empty(1, T_, H_, W_, Co, dtype=BF, device=dev)
+            wk = (torch.randn(Co, 27 * Ci, device=dev) * 0.02).to(BF); b = torch.zeros(Co, dtype=BF, device=dev)
+            med, mn = timeit(lambda: ops.causal_conv3d(x, wk, b, y), iters=5, warm=2)
+            fl = 2.0 * T_ * H_ * W_ * Co * 27 * Ci
+            print(f"causal conv3d {name}: {T_}x{H_}x{W_} {Ci}->{Co}: {med:.3f} ms  {fl/med/1e9:.0f} TF/s", flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

@@ -1,0 +1,186 @@
+// Causal 3x3x3 convolution over channels-last video activations as an implicit GEMM on the matrix cores, gfx950.
+//   y[n,t,h,w,co] = bias[co] + sum_{dt,dh,dw in 0..2} sum_ci x[n, max(t+dt-2, 0), h+dh-1, w+dw-1, ci] * Wk[co, (dt,dh,dw), ci]
+// (zero padding in h / w, the FIRST FRAME REPLICATED in front of t -- the causal padding of the CogVideoX VAE:
+// `ContextParallelCausalConv3d`, videotuna/models/cogvideo_sat/vae_modules/cp_enc_dec.py:356-433 with
+// `_fake_cp_pass_from_previous_rank` :228-273; diffusers' CogVideoXCausalConv3d behind cogvideo_pl.py:792-813).  Second kernel of the
+// next scope row (the VAE encoder: ~150 TFLOP per 49x480x720 sample, nearly all of it in these convolutions).
+//
+// GEMM view: M = N*T*H*W output positions, N = Cout, K = 27 * Cin; the K loop walks the 27 taps, Cin/64 K-tiles each.  Same
+// 128x128x64 tile, LDS-DMA staging, swizzle and MFMA loop as gemm_bf16.hip; the only difference is the A operand: the row a lane
+// fetches for output position m and tap (dt,dh,dw) is the input position m + delta(tap) -- or nothing (an out-of-range buffer
+// offset reads zeros) where the tap leaves the image.  No im2col buffer exists; each input row is fetched 27 times, from the L2
+// (a tile's halo is ~0.9 MB, shared with its neighbours on the same XCD).
+#include "gemm_epilogue.h"
+
+struct Conv3dParams {
+    GemmParams g;          // C = y, ldc, bias, M = positions, N = Cout (the epilogue's view); A / W = x / packed weight
+    int T, H, W, Cin;
+    long long ldx;         // position stride of x in elements (>= Cin)
+    long long x_rows;      // N*T*H*W
+};
+
+#define CV_BM 128
+#define CV_BN 128
+#define CV_BK 64
+#define CV_CS_LD 132
+#define CV_OOB 0x80000000u   // buffer offset that is always out of range (num_records is clamped to < 2^31): the fetch returns zeros
+
+__global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const GemmParams& p = cp.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nbm = (p.M + CV_BM - 1) / CV_BM, nbn = (p.N + CV_BN - 1) / CV_BN;
+    // XCD-aware id, then consecutive row tiles (neighbouring positions, shared halos) on the same XCD, column tiles inner
+    const int id = xcd_remap(blockIdx.x, nbm * nbn);
+    const int tile_m = id / nbn, tile_n = id % nbn;
+    const int row0 = tile_m * CV_BM, col0 = tile_n * CV_BN;
+    const int HW = cp.H * cp.W;
+
+    // A descriptor rooted two frames (+ one line + one pixel) before the tile: every tap of every row of the tile is reachable
+    // with a non-negative 31-bit byte offset
+    long long base_row = (long long)row0 - 2LL * HW - cp.W - 1;
+    if (base_row < 0) base_row = 0;
+    const long long a_rem = (cp.x_rows - base_row) * cp.ldx * 2;
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + base_row * cp.ldx, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
+    const long long w_rem = (long long)(p.N - col0) * p.ldw * 2;
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(p.W + (size_t)col0 * p.ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
+
+    // ---- LDS-DMA staging (see gemm_bf16.hip): wave w moves blocks w, w+4, w+8, w+12 (8 rows x 128 B each) of each operand ----
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int drl = lane >> 3, dcp = lane & 7;
+    const int chunk_off = (dcp ^ drl) << 4;
+    int w_voff[4];
+    int rt[4], rh[4], rw_[4];            // (t, h, w) of this lane's four A rows; rt < 0: row beyond M
+    long long rrel[4];                   // input row of the centre tap relative to base_row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drl;
+        w_voff[j] = row * p.ldw * 2 + chunk_off;
+        const long long m = (long long)row0 + row;
+        if (m < p.M) {
+            const int sp = (int)(m % HW);
+            rt[j] = (int)((m / HW) % cp.T);
+            rh[j] = sp / cp.W;
+            rw_[j] = sp - rh[j] * cp.W;
+        } else {
+            rt[j] = -1; rh[j] = 0; rw_[j] = 0;
+        }
+        rrel[j] = m - base_row;
+    }
+    const int kpt = cp.Cin / CV_BK;      // K-tiles per tap
+    unsigned a_voff[4];
+    auto set_tap = [&](int tap) {
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int tt = rt[j] + dt - 2;
+            tt = tt < 0 ? 0 : tt;                                   // causal: frames before the first one are the first one
+            const int hh = rh[j] + dh - 1, ww = rw_[j] + dw - 1;
+            const bool ok = rt[j] >= 0 && hh >= 0 && hh < cp.H && ww >= 0 && ww < cp.W;
+            const long long r = rrel[j] + (long long)(tt - rt[j]) * HW + (long long)(dh - 1) * cp.W + (dw - 1);
+            a_voff[j] = ok ? (unsigned)(r * cp.ldx * 2 + chunk_off) : CV_OOB;
+        }
+    };
+    int d_tap = 0, d_kc = 0;             // (tap, K-tile inside the tap) of the next K-tile to fetch
+    auto dma = [&](int buf) {
+        if (d_kc == 0) set_tap(d_tap);
+        const int a_soff = d_kc * CV_BK * 2;
+        const int w_soff = (d_tap * cp.Cin + d_kc * CV_BK) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* dst = smem + buf * 32768 + (wv + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, (int)a_voff[j], a_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 16384), 16, w_voff[j], w_soff, 0, 0);
+        }
+        if (++d_kc == kpt) { d_kc = 0; ++d_tap; }
+    };
+
+    f32x4 acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = 27 * kpt;
+    dma(0);
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) dma(buf ^ 1);
+        const char* As = smem + buf * 32768;
+        const char* Ws = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = (((ks * 4 + fq) ^ fx) << 4);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(As + (wm * 64 + t * 16 + frow) * 128 + coff);
+                wf[t] = *(const bf16x8*)(Ws + (wn * 64 + t * 16 + frow) * 128 + coff);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+        __syncthreads();       // its vmcnt(0) also retires the next tile's LDS-DMA
+    }
+
+    // ---------------- epilogue: two 64-row halves through LDS, bias, bf16 store ----------------
+    float* Cs = (float*)smem;
+    const int er = tid >> 5, ec = (tid & 31) * 4;
+    const int n = col0 + ec;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && n < p.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    *(f32x4*)(Cs + (tm * 16 + frow) * CV_CS_LD + wn * 64 + tn * 16 + fq * 4) = acc[tn][tm];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int ml = pass * 8 + er;
+            const int m = row0 + half * 64 + ml;
+            if (m < p.M && n < p.N) {
+                const f32x4 v = *(const f32x4*)(Cs + ml * CV_CS_LD + ec);
+                gemm_epilogue_store<EPI_BIAS, false>(p, m, n, v, bias4);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// x: bf16 [N, T, H, W, Cin] channels-last (position stride ldx >= Cin, a multiple of 8); wk: bf16 [Cout, 27 * Cin], tap-major
+// (dt, dh, dw, ci) -- i.e. torch's Conv3d weight [Cout, Cin, 3, 3, 3] permuted to [Cout, 3, 3, 3, Cin]; bias bf16 [Cout] or null;
+// y: bf16 [N, T, H, W, Cout] (position stride ldy).  Cin % 64 == 0, Cout % 4 == 0.
+extern "C" int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
+                                   int N, int T, int H, int W, int Cin, int Cout, void* stream) {
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % CV_BK) || (Cout % 4)) return VT_ERR_BAD_SHAPE;
+    if ((ldx % 8) || (ldy % 4) || ldx < Cin || ldy < Cout) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long rows = (long long)N * T * H * W;
+    // 31-bit byte offsets: rows of a tile and its taps span two frames + two lines on either side; M itself must fit an int
+    if (rows >= 0x7fffffffLL || (2LL * H * W + 2LL * W + 2 + 2 * CV_BM) * ldx * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    if (27LL * Cin * 2 * CV_BN >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    Conv3dParams cp;
+    GemmParams& p = cp.g;
+    p.A = (const bf16_t*)x; p.W = (const bf16_t*)wk; p.C = y; p.bias = (const bf16_t*)bias;
+    p.R = nullptr; p.gate_txt = nullptr; p.gate_vid = nullptr; p.C2 = nullptr; p.U = nullptr;
+    p.M = (int)rows; p.N = Cout; p.K = 27 * Cin; p.lda = (int)ldx; p.ldw = 27 * Cin; p.ldc = (int)ldy; p.ldr = 0; p.ldc2 = 0; p.ldu = 0;
+    p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = 1;
+    cp.T = T; cp.H = H; cp.W = W; cp.Cin = Cin; cp.ldx = ldx; cp.x_rows = rows;
+    const int nbm = (p.M + CV_BM - 1) / CV_BM, nbn = (Cout + CV_BN - 1) / CV_BN;
+    hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nbm * nbn), dim3(256), 0, (hipStream_t)stream, cp);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -123,8 +123,14 @@ int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* gamma, const 
  * [Cout, 27*Cin] = torch's Conv3d weight permuted to [Cout,3,3,3,Cin], bias bf16 [Cout] or NULL, y: bf16 [N,T,H,W,Cout].
  * Cin % 64 == 0, Cout % 4 == 0.  Replaces: ContextParallelCausalConv3d (cogvideo_sat/vae_modules/cp_enc_dec.py:356-433) /
  * diffusers CogVideoXCausalConv3d in the VAE encoder the reference runs at cogvideo_pl.py:792-813. */
-int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
-                        int N, int T, int H, int W, int Cin, int Cout, void* stream);
+int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, const void* res, long long ldr,
+                        void* y, long long ldy, int N, int T, int H, int W, int Cin, int Cout, void* stream);
+/* res (optional, bf16 [N,T,H,W,Cout], position stride ldr) is added to the result: the skip of the ResNet block (x + h,
+ * cp_enc_dec.py:776).  vt_downsample_conv2d_cl: the VAE's spatial downsample (DownSample3D.forward, cp_enc_dec.py:660-666): per
+ * frame, a zero line / column appended at the bottom / right, 3x3 convolution with stride 2; wk bf16 [Cout, 9*Cin] = Conv2d weight
+ * permuted to [Cout,3,3,Cin]; y bf16 [N,T,H/2,W/2,Cout]. */
+int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
+                            int N, int T, int H, int W, int Cin, int Cout, void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);

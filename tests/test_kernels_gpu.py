@@ -552,3 +552,20 @@ def test_causal_conv3d_channels_last(dev, N, T, H, W, Cin, Cout):
     y2 = torch.empty(N, T, H, W, Cout, dtype=BF, device=dev)
     ops.causal_conv3d(X[..., :Cin], ops.pack_conv3d_weight(w).to(dev, BF), None, y2)
     close(y2, ref - b, 1e-2, 1e-2 * ref.abs().max().item(), "causal conv3d, no bias")
+    r = rb(torch.randn(N, T, H, W, Cout, generator=g))                      # the ResNet block's skip, added in the epilogue
+    ops.causal_conv3d(X[..., :Cin], ops.pack_conv3d_weight(w).to(dev, BF), b.to(dev, BF), y2, residual=r.to(dev, BF))
+    close(y2, ref + r, 1e-2, 1e-2 * (ref + r).abs().max().item(), "causal conv3d + residual")
+
+
+@pytest.mark.parametrize("N,T,H,W,Cin,Cout", [(1, 2, 6, 8, 64, 64), (2, 3, 10, 14, 128, 128), (1, 1, 32, 20, 256, 64)])
+def test_downsample_conv2d_channels_last(dev, N, T, H, W, Cin, Cout):
+    """the VAE's spatial downsample (DownSample3D.forward, cp_enc_dec.py:660-666): F.pad (0,1,0,1) then Conv2d(3, stride 2) per frame"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = rb(torch.randn(N, T, H, W, Cin, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (9 * Cin) ** 0.5)); b = rb(torch.randn(Cout, generator=g))
+    xin = x.permute(0, 1, 4, 2, 3).reshape(N * T, Cin, H, W)
+    ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, b, stride=2).reshape(N, T, Cout, H // 2, W // 2).permute(0, 1, 3, 4, 2)
+    y = torch.empty(N, T, H // 2, W // 2, Cout, dtype=BF, device=dev)
+    ops.downsample_conv2d(x.to(dev, BF), ops.pack_conv_weight(w).to(dev, BF), b.to(dev, BF), y)
+    close(y, ref, 1e-2, 1e-2 * ref.abs().max().item(), "downsample conv2d")

@@ -13,8 +13,9 @@
 #include "gemm_epilogue.h"
 
 struct Conv3dParams {
-    GemmParams g;          // C = y, ldc, bias, M = positions, N = Cout (the epilogue's view); A / W = x / packed weight
-    int T, H, W, Cin;
+    GemmParams g;          // C = y, ldc, bias, R (residual), M = output positions, N = Cout (the epilogue's view); A / W = x / packed weight
+    int T, H, W, Cin;      // input frames / lines / pixels per sample, input channels
+    int Ho, Wo;            // output lines / pixels (H, W at stride 1; H/2, W/2 for the stride-2 downsample)
     long long ldx;         // position stride of x in elements (>= Cin)
     long long x_rows;      // N*T*H*W
 };
@@ -25,7 +26,11 @@ struct Conv3dParams {
 #define CV_CS_LD 132
 #define CV_OOB 0x80000000u   // buffer offset that is always out of range (num_records is clamped to < 2^31): the fetch returns zeros
 
+// KT = temporal taps (3: causal 3x3x3, 1: per-frame 3x3), STRIDE = spatial stride (1: padding 1 on all sides, 2: the VAE's
+// downsample -- no padding on top / left, one zero line / column at the bottom / right), EPI = EPI_BIAS or EPI_GATED_RES (+ residual)
+template <int KT, int STRIDE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
+    constexpr int PAD = STRIDE == 1 ? 1 : 0;
     __shared__ __attribute__((aligned(16))) char smem[65536];
     const GemmParams& p = cp.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,12 +40,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
     const int id = xcd_remap(blockIdx.x, nbm * nbn);
     const int tile_m = id / nbn, tile_n = id % nbn;
     const int row0 = tile_m * CV_BM, col0 = tile_n * CV_BN;
-    const int HW = cp.H * cp.W;
+    const int HW = cp.H * cp.W, HWo = cp.Ho * cp.Wo;
 
-    // A descriptor rooted two frames (+ one line + one pixel) before the tile: every tap of every row of the tile is reachable
-    // with a non-negative 31-bit byte offset
-    long long base_row = (long long)row0 - 2LL * HW - cp.W - 1;
-    if (base_row < 0) base_row = 0;
+    // A descriptor rooted at the first input FRAME the tile can touch (frame max(t0 - (KT-1), 0) of the first output position's
+    // sample): later output positions only reach the same or later frames, so all byte offsets are non-negative and, the host
+    // having bounded the span, fit 31 bits
+    long long base_row;
+    {
+        const long long nt = (long long)row0 / HWo;
+        const int t0 = (int)(nt % cp.T);
+        int tt = t0 - (KT - 1); tt = tt < 0 ? 0 : tt;
+        base_row = ((nt / cp.T) * cp.T + tt) * (long long)HW;
+    }
     const long long a_rem = (cp.x_rows - base_row) * cp.ldx * 2;
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + base_row * cp.ldx, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
     const long long w_rem = (long long)(p.N - col0) * p.ldw * 2;
@@ -51,22 +62,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
     const int drl = lane >> 3, dcp = lane & 7;
     const int chunk_off = (dcp ^ drl) << 4;
     int w_voff[4];
-    int rt[4], rh[4], rw_[4];            // (t, h, w) of this lane's four A rows; rt < 0: row beyond M
-    long long rrel[4];                   // input row of the centre tap relative to base_row
+    int rt[4], rh[4], rw_[4];            // (t, ho, wo) of this lane's four output rows; rt < 0: row beyond M
+    long long rfr[4];                    // first input row of the sample's frame 0, relative to base_row: (n * T) * H * W - base_row
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = 8 * (wv + 4 * j) + drl;
         w_voff[j] = row * p.ldw * 2 + chunk_off;
         const long long m = (long long)row0 + row;
         if (m < p.M) {
-            const int sp = (int)(m % HW);
-            rt[j] = (int)((m / HW) % cp.T);
-            rh[j] = sp / cp.W;
-            rw_[j] = sp - rh[j] * cp.W;
+            const int sp = (int)(m % HWo);
+            const long long nt = m / HWo;
+            rt[j] = (int)(nt % cp.T);
+            rh[j] = sp / cp.Wo;
+            rw_[j] = sp - rh[j] * cp.Wo;
+            rfr[j] = (nt / cp.T) * cp.T * (long long)HW - base_row;
         } else {
-            rt[j] = -1; rh[j] = 0; rw_[j] = 0;
+            rt[j] = -1; rh[j] = 0; rw_[j] = 0; rfr[j] = 0;
         }
-        rrel[j] = m - base_row;
     }
     const int kpt = cp.Cin / CV_BK;      // K-tiles per tap
     unsigned a_voff[4];
@@ -74,11 +86,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
         const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int tt = rt[j] + dt - 2;
+            int tt = rt[j] + dt - (KT - 1);
             tt = tt < 0 ? 0 : tt;                                   // causal: frames before the first one are the first one
-            const int hh = rh[j] + dh - 1, ww = rw_[j] + dw - 1;
+            const int hh = rh[j] * STRIDE + dh - PAD, ww = rw_[j] * STRIDE + dw - PAD;
             const bool ok = rt[j] >= 0 && hh >= 0 && hh < cp.H && ww >= 0 && ww < cp.W;
-            const long long r = rrel[j] + (long long)(tt - rt[j]) * HW + (long long)(dh - 1) * cp.W + (dw - 1);
+            const long long r = rfr[j] + (long long)tt * HW + (long long)hh * cp.W + ww;
             a_voff[j] = ok ? (unsigned)(r * cp.ldx * 2 + chunk_off) : CV_OOB;
         }
     };
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = 27 * kpt;
+    const int nk = KT * 9 * kpt;
     dma(0);
     __syncthreads();
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
@@ -154,33 +166,52 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
             const int m = row0 + half * 64 + ml;
             if (m < p.M && n < p.N) {
                 const f32x4 v = *(const f32x4*)(Cs + ml * CV_CS_LD + ec);
-                gemm_epilogue_store<EPI_BIAS, false>(p, m, n, v, bias4);
+                gemm_epilogue_store<EPI, false>(p, m, n, v, bias4);
             }
         }
         __syncthreads();
     }
 }
 
-// x: bf16 [N, T, H, W, Cin] channels-last (position stride ldx >= Cin, a multiple of 8); wk: bf16 [Cout, 27 * Cin], tap-major
-// (dt, dh, dw, ci) -- i.e. torch's Conv3d weight [Cout, Cin, 3, 3, 3] permuted to [Cout, 3, 3, 3, Cin]; bias bf16 [Cout] or null;
-// y: bf16 [N, T, H, W, Cout] (position stride ldy).  Cin % 64 == 0, Cout % 4 == 0.
-extern "C" int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
-                                   int N, int T, int H, int W, int Cin, int Cout, void* stream) {
+template <int KT, int STRIDE>
+static int conv_launch(const void* x, long long ldx, const void* wk, const void* bias, const void* res, long long ldr, void* y, long long ldy,
+                       int N, int T, int H, int W, int Cin, int Cout, hipStream_t st) {
     if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % CV_BK) || (Cout % 4)) return VT_ERR_BAD_SHAPE;
-    if ((ldx % 8) || (ldy % 4) || ldx < Cin || ldy < Cout) return VT_ERR_BAD_SHAPE;
-    if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y)) & 15) return VT_ERR_BAD_ALIGN;
-    const long long rows = (long long)N * T * H * W;
-    // 31-bit byte offsets: rows of a tile and its taps span two frames + two lines on either side; M itself must fit an int
-    if (rows >= 0x7fffffffLL || (2LL * H * W + 2LL * W + 2 + 2 * CV_BM) * ldx * 2 >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
-    if (27LL * Cin * 2 * CV_BN >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    if (STRIDE == 2 && ((H % 2) || (W % 2))) return VT_ERR_BAD_SHAPE;
+    if ((ldx % 8) || (ldy % 4) || ldx < Cin || ldy < Cout || (res != nullptr && ((ldr % 4) || ldr < Cout))) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) return VT_ERR_BAD_ALIGN;
+    const int Ho = H / STRIDE, Wo = W / STRIDE;
+    const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
+    // 31-bit byte offsets from the start of the first frame a tile touches: at most KT + 2 frames (a tile may end one sample and
+    // begin the next) plus the lines it covers
+    const long long span = ((long long)(KT + 2) * H * W + ((long long)CV_BM / Wo + 4) * STRIDE * W + 256) * ldx * 2;
+    if (rows_out >= 0x7fffffffLL || span >= 0x7fffffffLL || (long long)KT * 9 * Cin * 2 * CV_BN >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     Conv3dParams cp;
     GemmParams& p = cp.g;
     p.A = (const bf16_t*)x; p.W = (const bf16_t*)wk; p.C = y; p.bias = (const bf16_t*)bias;
-    p.R = nullptr; p.gate_txt = nullptr; p.gate_vid = nullptr; p.C2 = nullptr; p.U = nullptr;
-    p.M = (int)rows; p.N = Cout; p.K = 27 * Cin; p.lda = (int)ldx; p.ldw = 27 * Cin; p.ldc = (int)ldy; p.ldr = 0; p.ldc2 = 0; p.ldu = 0;
-    p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = 1;
-    cp.T = T; cp.H = H; cp.W = W; cp.Cin = Cin; cp.ldx = ldx; cp.x_rows = rows;
+    p.R = (const bf16_t*)res; p.gate_txt = nullptr; p.gate_vid = nullptr; p.C2 = nullptr; p.U = nullptr;
+    p.M = (int)rows_out; p.N = Cout; p.K = KT * 9 * Cin; p.lda = (int)ldx; p.ldw = KT * 9 * Cin; p.ldc = (int)ldy; p.ldr = (int)ldr;
+    p.ldc2 = 0; p.ldu = 0; p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = 1;
+    cp.T = T; cp.H = H; cp.W = W; cp.Cin = Cin; cp.Ho = Ho; cp.Wo = Wo; cp.ldx = ldx; cp.x_rows = rows_in;
     const int nbm = (p.M + CV_BM - 1) / CV_BM, nbn = (Cout + CV_BN - 1) / CV_BN;
-    hipLaunchKernelGGL(conv3d_cl_kernel, dim3(nbm * nbn), dim3(256), 0, (hipStream_t)stream, cp);
+    if (res != nullptr) hipLaunchKernelGGL((conv3d_cl_kernel<KT, STRIDE, EPI_GATED_RES>), dim3(nbm * nbn), dim3(256), 0, st, cp);
+    else hipLaunchKernelGGL((conv3d_cl_kernel<KT, STRIDE, EPI_BIAS>), dim3(nbm * nbn), dim3(256), 0, st, cp);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// x: bf16 [N, T, H, W, Cin] channels-last (position stride ldx >= Cin, a multiple of 8); wk: bf16 [Cout, 27 * Cin], tap-major
+// (dt, dh, dw, ci) -- i.e. torch's Conv3d weight [Cout, Cin, 3, 3, 3] permuted to [Cout, 3, 3, 3, Cin]; bias bf16 [Cout] or null;
+// res: optional bf16 [N, T, H, W, Cout] (position stride ldr) added to the result (the ResNet block's skip); y: bf16
+// [N, T, H, W, Cout] (position stride ldy).  Cin % 64 == 0, Cout % 4 == 0.
+extern "C" int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void* bias, const void* res, long long ldr,
+                                   void* y, long long ldy, int N, int T, int H, int W, int Cin, int Cout, void* stream) {
+    return conv_launch<3, 1>(x, ldx, wk, bias, res, ldr, y, ldy, N, T, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+// The VAE's spatial downsample: per frame, one zero line / column appended at the bottom / right, 3x3 convolution with stride 2 and
+// no other padding (DownSample3D.forward, cp_enc_dec.py:660-666).  wk: bf16 [Cout, 9 * Cin] = Conv2d weight permuted to
+// [Cout, 3, 3, Cin]; y: bf16 [N, T, H/2, W/2, Cout].  H, W even.
+extern "C" int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
+                                       int N, int T, int H, int W, int Cin, int Cout, void* stream) {
+    return conv_launch<1, 2>(x, ldx, wk, bias, nullptr, 0, y, ldy, N, T, H, W, Cin, Cout, (hipStream_t)stream);
 }

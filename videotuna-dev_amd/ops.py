@@ -221,26 +221,55 @@ def groupnorm_silu(x, gamma, beta, y, groups: int = 32, eps: float = 1e-6, silu:
     return y
 
 
-def pack_conv3d_weight(w: torch.Tensor) -> torch.Tensor:
-    """torch Conv3d weight [Cout, Cin, 3, 3, 3] -> [Cout, 27 * Cin] tap-major (dt, dh, dw, ci), the layout vt_causal_conv3d_cl reads"""
-    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
-        raise ValueError(f"expected a [Cout, Cin, 3, 3, 3] weight, got {tuple(w.shape)}")
-    return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """torch Conv3d weight [Cout, Cin, 3, 3, 3] (or Conv2d [Cout, Cin, 3, 3]) -> [Cout, taps * Cin], tap-major with the input
+    channel innermost: the layout vt_causal_conv3d_cl / vt_downsample_conv2d_cl read"""
+    if w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3):
+        return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+    if w.dim() == 4 and tuple(w.shape[2:]) == (3, 3):
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    raise ValueError(f"expected a [Cout, Cin, 3, 3, 3] or [Cout, Cin, 3, 3] weight, got {tuple(w.shape)}")
 
 
-def causal_conv3d(x, wk, bias, y):
-    """x bf16 [N,T,H,W,Cin] channels-last, wk = pack_conv3d_weight(weight) bf16, bias bf16 [Cout] or None, y bf16 [N,T,H,W,Cout]"""
+pack_conv3d_weight = pack_conv_weight
+
+
+def _cl_check(t, nm):
+    ld = t.stride(3)
+    N, T, H, W, _ = t.shape
+    if t.stride(2) != W * ld or t.stride(1) != H * W * ld or t.stride(0) != T * H * W * ld:
+        raise ValueError(f"{nm}: positions must be uniformly strided (channels-last, only the channel axis may be a slice)")
+
+
+def causal_conv3d(x, wk, bias, y, residual=None):
+    """x bf16 [N,T,H,W,Cin] channels-last, wk = pack_conv_weight(weight) bf16, bias bf16 [Cout] or None, y bf16 [N,T,H,W,Cout];
+    residual (optional, like y) is added to the result"""
     _req(x, BF16, "x", 5); _req(y, BF16, "y", 5); _req(wk, BF16, "wk", 2)
     N, T, H, W, Cin = x.shape
     Cout = y.shape[4]
     if tuple(y.shape[:4]) != (N, T, H, W) or tuple(wk.shape) != (Cout, 27 * Cin) or not wk.is_contiguous():
         raise ValueError(f"shape mismatch: x {tuple(x.shape)} wk {tuple(wk.shape)} y {tuple(y.shape)}")
-    for t, nm in ((x, "x"), (y, "y")):
-        ld = t.stride(3)
-        if t.stride(2) != W * ld or t.stride(1) != H * W * ld or t.stride(0) != T * H * W * ld:
-            raise ValueError(f"{nm}: positions must be uniformly strided (channels-last, only the channel axis may be a slice)")
-    check(load_library().vt_causal_conv3d_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), y.data_ptr(), y.stride(3),
+    _cl_check(x, "x"); _cl_check(y, "y")
+    if residual is not None:
+        _req(residual, BF16, "residual", 5); _cl_check(residual, "residual")
+        if tuple(residual.shape) != tuple(y.shape):
+            raise ValueError("residual must have the shape of y")
+    check(load_library().vt_causal_conv3d_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), _p(residual),
+                                             0 if residual is None else residual.stride(3), y.data_ptr(), y.stride(3),
                                              N, T, H, W, Cin, Cout, _stream()), "vt_causal_conv3d_cl")
+    return y
+
+
+def downsample_conv2d(x, wk, bias, y):
+    """per frame: zero line / column at the bottom / right, 3x3 conv, stride 2.  x bf16 [N,T,H,W,Cin], y bf16 [N,T,H/2,W/2,Cout]"""
+    _req(x, BF16, "x", 5); _req(y, BF16, "y", 5); _req(wk, BF16, "wk", 2)
+    N, T, H, W, Cin = x.shape
+    Cout = y.shape[4]
+    if tuple(y.shape[:4]) != (N, T, H // 2, W // 2) or tuple(wk.shape) != (Cout, 9 * Cin) or not wk.is_contiguous():
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)} wk {tuple(wk.shape)} y {tuple(y.shape)}")
+    _cl_check(x, "x"); _cl_check(y, "y")
+    check(load_library().vt_downsample_conv2d_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), y.data_ptr(), y.stride(3),
+                                                 N, T, H, W, Cin, Cout, _stream()), "vt_downsample_conv2d_cl")
     return y
 
 

@@ -131,6 +131,9 @@ int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void
  * permuted to [Cout,3,3,Cin]; y bf16 [N,T,H/2,W/2,Cout]. */
 int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
                             int N, int T, int H, int W, int Cin, int Cout, void* stream);
+/* Temporal compression of the VAE's DownSample3D (cp_enc_dec.py:640-657): frame 0 kept, frames 1.. averaged in consecutive pairs
+ * (a trailing odd frame is dropped): x bf16 [N,T,HW,C] -> y bf16 [N, 1 + (T-1)/2, HW, C], channels-last. */
+int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);

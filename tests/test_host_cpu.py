@@ -327,3 +327,28 @@ def test_t5_encoder_host_side(tmp_path):
         emb(["a prompt"])
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 4, dtype=torch.long), attention_mask=torch.ones(1, 4))
+
+
+def test_vae_encoder_host_side():
+    """module tree / parameter names of the VAE encoder = the reference's in-tree twin (and the oracle's init_params), shapes, and
+    the reference's call surface .encode(x).latent_dist / .config.scaling_factor; no CPU path"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vae_oracle as V
+    from vt355.vae import CogVideoXVaeEncoder, DiagonalGaussianDistribution
+    cfg = V.tiny_config(ch=64)
+    m = CogVideoXVaeEncoder(ch=cfg.ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, z_channels=cfg.z_channels,
+                            temporal_compress_times=cfg.temporal_compress_times)
+    want = V.init_params(cfg, 0)
+    got = m.state_dict()
+    assert set(got) == set(want), sorted(set(got) ^ set(want))[:6]
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(v.shape), k
+    m.load_state_dict(want)
+    assert abs(m.config.scaling_factor - 1.15258426) < 1e-9
+    d = DiagonalGaussianDistribution(torch.zeros(1, 8, 2, 3, 3))
+    assert tuple(d.sample().shape) == (1, 4, 2, 3, 3) and torch.equal(d.mode(), torch.zeros(1, 4, 2, 3, 3))
+    full = CogVideoXVaeEncoder()
+    assert sum(p.numel() for p in full.parameters()) > 50e6          # CogVideoX encoder: ch 128, (1,2,2,4), 3 blocks per level
+    with pytest.raises((ValueError, RuntimeError)):
+        m(torch.zeros(1, 3, 5, 8, 8))

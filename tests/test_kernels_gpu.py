@@ -569,3 +569,24 @@ def test_downsample_conv2d_channels_last(dev, N, T, H, W, Cin, Cout):
     y = torch.empty(N, T, H // 2, W // 2, Cout, dtype=BF, device=dev)
     ops.downsample_conv2d(x.to(dev, BF), ops.pack_conv_weight(w).to(dev, BF), b.to(dev, BF), y)
     close(y, ref, 1e-2, 1e-2 * ref.abs().max().item(), "downsample conv2d")
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 8, 49])
+def test_temporal_pool(dev, T):
+    """DownSample3D's compress_time branch (cp_enc_dec.py:640-657): first frame kept, avg_pool1d(2, 2) over the rest"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(T)
+    N, H, W, C = 2, 3, 5, 64
+    x = rb(torch.randn(N, T, H, W, C, generator=g))
+    if T > 1:
+        xt = x.permute(0, 2, 3, 4, 1).reshape(N * H * W, C, T)
+        rest = F.avg_pool1d(xt[..., 1:], kernel_size=2, stride=2) if T > 2 else xt[..., 1:1]
+        ref = torch.cat([xt[..., :1], rest], dim=-1)
+        To = ref.shape[-1]
+        ref = ref.reshape(N, H, W, C, To).permute(0, 4, 1, 2, 3)
+    else:
+        ref, To = x, 1
+    assert To == 1 + (T - 1) // 2
+    y = torch.empty(N, To, H, W, C, dtype=BF, device=dev)
+    ops.temporal_pool(x.to(dev, BF), y)
+    close(y, ref, 1e-2, 1e-2, "temporal pool")

@@ -374,3 +374,26 @@ def test_full_finetune_loss_curve_tracks_the_oracle(dev):
     for a, b in zip(cd, cr):
         assert abs(a - b) / b < 1e-3, (cd, cr)
     assert cr[-1] < 0.99 * cr[0] and cd[-1] < 0.99 * cd[0], (cd, cr)
+
+
+@pytest.mark.parametrize("T,H,W", [(9, 16, 24), (1, 8, 12), (5, 24, 20)])
+def test_vae_encoder_matches_oracle(dev, T, H, W):
+    """The CogVideoX VAE encoder on the vt355 kernels (channels-last implicit-GEMM causal convolutions, GroupNorm+SiLU, temporal pool,
+    stride-2 downsample, 1x1x1 shortcut GEMM) against oracle/vae_oracle.py -- itself pinned bit for bit to the reference's in-tree
+    ContextParallelEncoder3D.  bf16 activations vs the fp32 oracle on the bf16-rounded weights; a single frame (image) too."""
+    import vae_oracle as V
+    from vt355.vae import CogVideoXVaeEncoder
+    cfg = V.tiny_config(ch=64)
+    m = CogVideoXVaeEncoder(ch=cfg.ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, z_channels=cfg.z_channels,
+                            temporal_compress_times=cfg.temporal_compress_times).init_weights(3).to(dev)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(T * H)
+    x = torch.randn(2, 3, T, H, W, generator=g).clamp(-1, 1).to(torch.bfloat16)
+    out = m(x.to(dev))
+    ref = V.encoder_forward(P, cfg, x.float())
+    assert tuple(out.shape) == tuple(ref.shape)
+    err = (out.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(out.float().cpu().reshape(-1), ref.reshape(-1), dim=0).item()
+    assert err < 4e-2 and cos > 0.999, (err, cos)
+    lat = m.encode(x.to(dev)).latent_dist.sample() * m.config.scaling_factor
+    assert tuple(lat.shape) == (2, cfg.z_channels) + tuple(ref.shape[2:]) and torch.isfinite(lat).all()

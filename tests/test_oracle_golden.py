@@ -163,3 +163,21 @@ def test_t5_oracle_matches_transformers_golden():
     # bucketing known answers: 0 -> 0, +1 -> 17, -1 -> 1, far left / right clamp to 15 / 31
     rel = torch.tensor([0, 1, -1, 7, -8, 200, -200])
     assert T.relative_position_bucket(rel, 32, 128).tolist() == [0, 17, 1, 23, 8, 31, 15]
+
+
+def test_vae_encoder_oracle_matches_reference_twin_golden():
+    """oracle/vae_oracle.py against the output of the reference's own ContextParallelEncoder3D (cogvideo_sat/vae_modules/
+    cp_enc_dec.py:779-907) on seeded weights (tests/golden/make_golden_vae.py): causal padding, ResNet blocks, temporal + spatial
+    downsampling, 9 frames -> 3 latent frames."""
+    import vae_oracle as V
+    g = np.load(os.path.join(G, "vae_encoder_tiny.npz"))
+    cfg = V.tiny_config()
+    P = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("P.")}
+    out = V.encoder_forward(P, cfg, torch.from_numpy(g["x"]))
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape == (1, 8, 3, 4, 6)
+    assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    mom = torch.randn(2, 8, 3, 4, 6)
+    eps = torch.randn(2, 4, 3, 4, 6)
+    lat = V.sample_latent(mom, eps, 0.7)
+    assert torch.allclose(lat, (mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * eps) * 0.7)

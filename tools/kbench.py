@@ -172,6 +172,43 @@ def main():
             med, mn = timeit(lambda: ops.causal_conv3d(x, wk, b, y), iters=5, warm=2)
             fl = 2.0 * T_ * H_ * W_ * Co * 27 * Ci
             print(f"causal conv3d {name}: {T_}x{H_}x{W_} {Ci}->{Co}: {med:.3f} ms  {fl/med/1e9:.0f} TF/s", flush=True)
+    if "vae" in which:        # the CogVideoX VAE encoder (random weights) on one 49x480x720 clip -- or fewer frames: kbench.py vae 13
+        from vt355.vae import CogVideoXVaeEncoder
+        frames = int(next((a for a in sys.argv[1:] if a.isdigit()), "49"))
+        with torch.device(dev):
+            enc = CogVideoXVaeEncoder()
+        gw = torch.Generator(device=dev).manual_seed(2)
+        with torch.no_grad():
+            for n_, p_ in enc.named_parameters():
+                if p_.dim() > 1:
+                    p_.normal_(0.0, 1.0 / p_[0].numel() ** 0.5, generator=gw)
+                elif n_.endswith("weight"):
+                    p_.fill_(1.0)
+                else:
+                    p_.zero_()
+        x = torch.rand(1, 3, frames, 480, 720, device=dev).mul_(2).sub_(1).to(BF)
+        # FLOPs of the convolutions / shortcut GEMMs at their true channel counts
+        fl, T_, H_, W_ = 0.0, frames, 480, 720
+        c = enc.config
+        cin = c.in_channels
+        fl += 2.0 * T_ * H_ * W_ * c.ch * 27 * cin
+        prev = c.ch
+        for i, mlt in enumerate(c.ch_mult):
+            co = c.ch * mlt
+            for j in range(c.num_res_blocks):
+                ci = prev if j == 0 else co
+                fl += 2.0 * T_ * H_ * W_ * (27 * ci * co + 27 * co * co + (ci * co if ci != co else 0))
+            prev = co
+            if i != len(c.ch_mult) - 1:
+                if i < 2 and T_ > 1:
+                    T_ = 1 + (T_ - 1) // 2
+                H_, W_ = H_ // 2, W_ // 2
+                fl += 2.0 * T_ * H_ * W_ * 9 * co * co
+        fl += 2 * 2.0 * T_ * H_ * W_ * 2 * 27 * prev * prev + 2.0 * T_ * H_ * W_ * 27 * prev * 32
+        torch.cuda.reset_peak_memory_stats()
+        med, mn = timeit(lambda: enc(x), iters=3, warm=1)
+        print(f"CogVideoX VAE encode, 1 x {frames}x480x720: {med:.1f} ms (min {mn:.1f})  {fl/1e12:.1f} TFLOP -> {fl/med/1e9:.0f} TFLOP/s, "
+              f"peak HBM {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
     if "red" in which:        # token-axis reductions: bias / adaLN column sums (full fine-tune) and the LoRA skinny products
         M = 2 * S
         x = torch.randn(M, d, device=dev).to(BF); y = torch.randn(M, d, device=dev).to(BF)

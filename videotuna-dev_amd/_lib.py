@@ -41,6 +41,7 @@ PROTOTYPES = {
     "vt_groupnorm_silu_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _ll, _i, _i, _f, _i, _fp, _ll, _vp],
     "vt_causal_conv3d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     "vt_downsample_conv2d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
+    "vt_temporal_pool_cl": [_vp, _ll, _vp, _ll, _i, _i, _ll, _i, _vp],
     "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],
     "vt_gated_gelu_bf16": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,

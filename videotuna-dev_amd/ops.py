@@ -273,6 +273,18 @@ def downsample_conv2d(x, wk, bias, y):
     return y
 
 
+def temporal_pool(x, y):
+    """x bf16 [N,T,H,W,C] -> y bf16 [N, 1 + (T-1)//2, H, W, C]: first frame kept, the rest averaged in pairs (VAE DownSample3D)"""
+    _req(x, BF16, "x", 5); _req(y, BF16, "y", 5)
+    N, T, H, W, C = x.shape
+    if tuple(y.shape) != (N, 1 + (T - 1) // 2, H, W, C):
+        raise ValueError(f"y must be {(N, 1 + (T - 1) // 2, H, W, C)}, got {tuple(y.shape)}")
+    _cl_check(x, "x"); _cl_check(y, "y")
+    check(load_library().vt_temporal_pool_cl(x.data_ptr(), x.stride(3), y.data_ptr(), y.stride(3), N, T, H * W, C, _stream()),
+          "vt_temporal_pool_cl")
+    return y
+
+
 def rmsnorm(x, w, y, eps: float = 1e-6):
     """T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w (rows of a 2-d bf16 tensor)"""
     _req(x, BF16, "x", 2); _req(y, BF16, "y", 2); _req(w, BF16, "w", 1)

@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--text-encoder", action="store_true",
                     help="extra data point: the frozen T5-XXL encoder (vt355.t5, random weights) produces every micro-batch's text "
                          "embeddings inside the loop, one step ahead on a side stream (SURVEY 8(f) row 1); default: pre-encoded text")
+    ap.add_argument("--vae-encoder", action="store_true",
+                    help="extra data point: every sample's latents come from the CogVideoX VAE encoder (vt355.vae, random weights) run on a "
+                         "raw [3,49,480,720] clip inside the loop, one step ahead on a side stream -- the reference encodes online "
+                         "(cogvideo_pl.py:792-813); default: pre-encoded latents")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
     args = ap.parse_args()
@@ -129,8 +133,34 @@ def main():
                     p.add_(1.0)
         side = torch.cuda.Stream(device=dev)
 
+    vae = None
+    if args.vae_encoder:
+        from vt355.vae import CogVideoXVaeEncoder
+        with torch.device(dev):
+            vae = CogVideoXVaeEncoder()
+        with torch.no_grad():
+            for name, p in vae.named_parameters():
+                if p.dim() > 1:
+                    p.normal_(0.0, 1.0 / p[0].numel() ** 0.5, generator=gen)
+                elif name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+        if side is None:
+            side = torch.cuda.Stream(device=dev)
+
     def make_batch():
-        x0 = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
+        if vae is not None:                             # raw clips -> frozen VAE encoder on the side stream, sample by sample
+            clips = torch.rand(B, 3, 49, 480, 720, device=dev, generator=dgen).mul_(2).sub_(1).to(torch.bfloat16)
+            clips.record_stream(side)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                lat = [vae.encode(clips[b:b + 1]).latent_dist.sample() * vae.config.scaling_factor for b in range(B)]
+                x0 = torch.cat(lat, 0).permute(0, 2, 1, 3, 4).contiguous()          # [B,C,F,H,W] -> [B,F,C,H,W] (cogvideo_pl.py:817-819)
+                ev_x = torch.cuda.Event(); ev_x.record(side)
+            x0 = (x0, ev_x)
+        else:
+            x0 = torch.randn(B, Fr, C, Hh, Ww, device=dev, generator=dgen)
         if t5 is not None:                              # token ids -> frozen encoder on the side stream; the DiT waits on the event
             ids = torch.randint(0, 32128, (B, St), device=dev, generator=dgen)
             side.wait_stream(torch.cuda.current_stream())
@@ -151,11 +181,15 @@ def main():
     def step():
         nonlocal batches
         nxt = None
-        if t5 is not None:                        # the NEXT step's prompts are encoded while this step's DiT runs
+        if t5 is not None or vae is not None:     # the NEXT step's prompts / clips are encoded while this step's DiT runs
             nxt = [make_batch() for _ in range(args.accum)]
         opt.zero_grad()
         for mb in range(args.accum):
             x0, text, noise, t = batches[mb]
+            if isinstance(x0, tuple):
+                x0, ev_x = x0
+                torch.cuda.current_stream().wait_event(ev_x)
+                x0.record_stream(torch.cuda.current_stream())
             if isinstance(text, tuple):
                 text, ev = text
                 torch.cuda.current_stream().wait_event(ev)
@@ -247,7 +281,9 @@ def main():
                        "parallelism": f"dp{world}", "recompute": recompute_note,
                        "weights": "seeded random init (no checkpoints offline)",
                        "text": ("T5-XXL encoder (vt355.t5, random weights) in the loop, one step ahead on a side stream"
-                                if args.text_encoder else "pre-encoded prompt embeddings (synthetic)")},
+                                if args.text_encoder else "pre-encoded prompt embeddings (synthetic)"),
+                       "latents": ("CogVideoX VAE encoder (vt355.vae, random weights) on raw 49x480x720 clips in the loop, one step ahead "
+                                   "on a side stream" if args.vae_encoder else "pre-encoded latents (synthetic)")},
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,

@@ -397,3 +397,8 @@ def test_vae_encoder_matches_oracle(dev, T, H, W):
     assert err < 4e-2 and cos > 0.999, (err, cos)
     lat = m.encode(x.to(dev)).latent_dist.sample() * m.config.scaling_factor
     assert tuple(lat.shape) == (2, cfg.z_channels) + tuple(ref.shape[2:]) and torch.isfinite(lat).all()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    eps = torch.randn(ref[:1, :cfg.z_channels].shape, generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    one = m.latents(x[0].to(dev), generator=gen)                     # the workflow's first_stage callable: one clip [3,T,H,W]
+    want = V.sample_latent(out[:1].float(), eps, m.config.scaling_factor)
+    assert torch.allclose(one, want, rtol=1e-5, atol=1e-5)

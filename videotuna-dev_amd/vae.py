@@ -220,3 +220,11 @@ class CogVideoXVaeEncoder(nn.Module):
     def encode(self, x: torch.Tensor):
         """``.encode(x).latent_dist.sample() * .config.scaling_factor`` as the reference calls it (cogvideo_pl.py:792-806)"""
         return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(self.forward(x)))
+
+    def latents(self, video: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """one clip [3, T, H, W] (or a batch [B, 3, T, H, W]) -> sampled latents * scaling_factor, [B, z, T', H', W'] fp32: what
+        ``encode_video`` + ``get_batch_input`` compute per sample (cogvideo_pl.py:792-806); the callable to pass as the workflow's
+        ``first_stage``"""
+        if video.dim() == 4:
+            video = video.unsqueeze(0)
+        return self.encode(video).latent_dist.sample(generator) * self.config.scaling_factor

@@ -402,3 +402,59 @@ def test_vae_encoder_matches_oracle(dev, T, H, W):
     one = m.latents(x[0].to(dev), generator=gen)                     # the workflow's first_stage callable: one clip [3,T,H,W]
     want = V.sample_latent(out[:1].float(), eps, m.config.scaling_factor)
     assert torch.allclose(one, want, rtol=3e-2, atol=3e-2)           # B=1 vs B=2 launch: GroupNorm's atomic sums differ in the last bits
+
+
+def test_training_step_from_raw_batch_through_both_encoders(dev):
+    """The reference's whole step on the device: a raw {"video", "caption"} batch -> CogVideoX VAE encoder (per clip, sample *
+    scaling_factor) + T5 text encoder -> add_noise -> DiT -> loss -> LoRA gradients (cogvideo_pl.py:792-887), with the encoders
+    handed to the workflow as first_stage / cond_stage and, a second time, run one batch ahead by EncoderPrefetcher.  The loss must
+    equal the one obtained from the same encodings fed as a pre-encoded batch under the same RNG state."""
+    import cogvideox_oracle as O
+    from vt355.lora import LoraConfig
+    from vt355.prefetch import EncoderPrefetcher
+    from vt355.selfcheck import CFG_KEYS
+    from vt355.t5 import FrozenT5Embedder, T5EncoderModel
+    from vt355.vae import CogVideoXVaeEncoder
+    from vt355.workflow import CogVideoXWorkFlow
+    cfg = O.tiny_config()
+    enc = CogVideoXVaeEncoder(ch=64, ch_mult=(1, 2, 2), num_res_blocks=1, z_channels=16, temporal_compress_times=4).init_weights(1).to(dev)
+    t5 = T5EncoderModel(vocab_size=50, d_model=cfg.text_embed_dim, d_kv=64, d_ff=128, num_layers=2, num_heads=2).init_weights(2).to(dev)
+    tok = lambda text, **kw: {"input_ids": torch.tensor([[(ord(ch) * 7 + i) % 50 for i, ch in enumerate(s.ljust(kw["max_length"]))][:kw["max_length"]]
+                                                          for s in text])}
+    emb = FrozenT5Embedder(tokenizer=tok, transformer=t5, device=dev, max_length=cfg.max_text_seq_length)
+    gen = torch.Generator(device=dev)
+    wf = CogVideoXWorkFlow(denoiser_config={"target": "vt355.dit.CogVideoXTransformer3DModel", "params": {k: getattr(cfg, k) for k in CFG_KEYS}},
+                           scheduler_config={"target": "vt355.scheduler.CogVideoXDPMScheduler"},
+                           adapter_config=LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]),
+                           first_stage=lambda v: enc.latents(v, generator=gen), cond_stage=emb)
+    wf.model.base_model.model.init_weights(3)        # the module allocates its weights uninitialised (they come from a checkpoint)
+    wf = wf.to(dev)
+    st = wf.model._lora_state
+    with torch.no_grad():               # peft's B = 0 init hides the adapters: randomise so that every gradient is exercised
+        for p, (layer, kind, j) in zip(st.params, st._index):
+            if kind == "B":
+                p.normal_(0.0, 0.02)
+    st.mark_changed()
+    g = torch.Generator().manual_seed(8)
+    clips = [torch.randn(3, 5, 24, 32, generator=g).clamp(-1, 1).to(dev) for _ in range(2)]      # 5 frames, 24x32 -> latents [16, 2, 6, 8]
+    batch = {"video": clips, "caption": ["a red kite over the sea", "two cats"]}
+    gen.manual_seed(11); torch.manual_seed(5)
+    st.grad.zero_()
+    loss = wf.training_step(batch)
+    loss.backward()
+    assert torch.isfinite(loss) and st.grad.abs().max().item() > 0
+    # the same encodings as a pre-encoded batch, same RNG state for noise / timesteps
+    gen.manual_seed(11)
+    pre = wf.encode_raw_batch(batch)
+    assert tuple(pre["latents"].shape) == (2, 16, 2, 6, 8) and tuple(pre["prompt_embeds"].shape) == (2, cfg.max_text_seq_length, cfg.text_embed_dim)
+    torch.manual_seed(5)
+    loss2 = wf.training_step(pre)
+    assert abs(loss2.item() - loss.item()) < 2e-2 * abs(loss.item()), (loss.item(), loss2.item())
+    # and one batch ahead on the side stream
+    gen.manual_seed(11)
+    it = iter(EncoderPrefetcher([batch, batch], encode=wf.encode_raw_batch, device=dev))
+    first = next(it)
+    torch.manual_seed(5)
+    loss3 = wf.training_step(first)
+    assert abs(loss3.item() - loss.item()) < 2e-2 * abs(loss.item()), (loss.item(), loss3.item())
+    assert len(list(it)) == 1

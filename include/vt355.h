@@ -131,6 +131,10 @@ int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk, const void
  * permuted to [Cout,3,3,Cin]; y bf16 [N,T,H/2,W/2,Cout]. */
 int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
                             int N, int T, int H, int W, int Cin, int Cout, void* stream);
+/* The encoder's first convolution (RGB): x bf16 [N,T,H,W,8] (8 channels per position, unused ones zero), wk bf16 [Cout, 32*8] =
+ * the Conv3d weight as (tap, channel) with taps 27..31 and channels >= Cin zero; 8 taps per K-tile instead of one. */
+int vt_causal_conv3d_in8_cl(const void* x, const void* wk, const void* bias, void* y, long long ldy,
+                            int N, int T, int H, int W, int Cout, void* stream);
 /* Temporal compression of the VAE's DownSample3D (cp_enc_dec.py:640-657): frame 0 kept, frames 1.. averaged in consecutive pairs
  * (a trailing odd frame is dropped): x bf16 [N,T,HW,C] -> y bf16 [N, 1 + (T-1)/2, HW, C], channels-last. */
 int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, void* stream);

@@ -590,3 +590,19 @@ def test_temporal_pool(dev, T):
     y = torch.empty(N, To, H, W, C, dtype=BF, device=dev)
     ops.temporal_pool(x.to(dev, BF), y)
     close(y, ref, 1e-2, 1e-2, "temporal pool")
+
+
+@pytest.mark.parametrize("N,T,H,W,Cin,Cout", [(1, 3, 6, 9, 3, 64), (2, 5, 12, 10, 3, 128), (1, 1, 8, 8, 8, 132)])
+def test_causal_conv3d_rgb_input(dev, N, T, H, W, Cin, Cout):
+    """the encoder's first convolution: 8 channels per position (Cin of them used), 8 taps per K-tile, vs fp32 F.conv3d"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(H * W + Cout)
+    x = rb(torch.randn(N, T, H, W, Cin, generator=g))
+    w = rb(torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (1.0 / (27 * Cin) ** 0.5)); b = rb(torch.randn(Cout, generator=g))
+    xin = x.permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(torch.cat([xin[:, :, :1]] * 2 + [xin], dim=2), w, b, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+    x8 = torch.zeros(N, T, H, W, 8, dtype=BF, device=dev)
+    x8[..., :Cin] = x.to(dev, BF)
+    y = torch.empty(N, T, H, W, Cout, dtype=BF, device=dev)
+    ops.causal_conv3d_in8(x8, ops.pack_conv_in8_weight(w).to(dev, BF), b.to(dev, BF), y)
+    close(y, ref, 1e-2, 1e-2 * ref.abs().max().item(), "first conv (8-channel input)")

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "vt_groupnorm_ws_bytes": [_i, _i],
     "vt_groupnorm_silu_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _ll, _i, _i, _f, _i, _fp, _ll, _vp],
     "vt_causal_conv3d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
+    "vt_causal_conv3d_in8_cl": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp],
     "vt_downsample_conv2d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     "vt_temporal_pool_cl": [_vp, _ll, _vp, _ll, _i, _i, _ll, _i, _vp],
     "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],

@@ -27,8 +27,10 @@ struct Conv3dParams {
 #define CV_OOB 0x80000000u   // buffer offset that is always out of range (num_records is clamped to < 2^31): the fetch returns zeros
 
 // KT = temporal taps (3: causal 3x3x3, 1: per-frame 3x3), STRIDE = spatial stride (1: padding 1 on all sides, 2: the VAE's
-// downsample -- no padding on top / left, one zero line / column at the bottom / right), EPI = EPI_BIAS or EPI_GATED_RES (+ residual)
-template <int KT, int STRIDE, int EPI>
+// downsample -- no padding on top / left, one zero line / column at the bottom / right), EPI = EPI_BIAS or EPI_GATED_RES (+ residual).
+// IN8: the first convolution of the encoder (RGB input): x has 8 channels per position (3 used) = ONE 16-byte chunk, and a K-tile
+// of 64 holds 8 TAPS x 8 channels instead of 64 channels of one tap -- 4 K-tiles (32 tap slots, 27 used) instead of 27.
+template <int KT, int STRIDE, int EPI, bool IN8 = false>
 __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
     constexpr int PAD = STRIDE == 1 ? 1 : 0;
     __shared__ __attribute__((aligned(16))) char smem[65536];
@@ -80,25 +82,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
             rt[j] = -1; rh[j] = 0; rw_[j] = 0; rfr[j] = 0;
         }
     }
-    const int kpt = cp.Cin / CV_BK;      // K-tiles per tap
+    const int kpt = IN8 ? 1 : cp.Cin / CV_BK;      // K-tiles per tap (IN8: per group of 8 taps)
     unsigned a_voff[4];
     auto set_tap = [&](int tap) {
+        if (IN8) tap = tap * 8 + (dcp ^ drl);       // this lane's chunk of the K-tile IS a tap: group `tap`, slot = logical chunk
         const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int tt = rt[j] + dt - (KT - 1);
             tt = tt < 0 ? 0 : tt;                                   // causal: frames before the first one are the first one
             const int hh = rh[j] * STRIDE + dh - PAD, ww = rw_[j] * STRIDE + dw - PAD;
-            const bool ok = rt[j] >= 0 && hh >= 0 && hh < cp.H && ww >= 0 && ww < cp.W;
+            const bool ok = rt[j] >= 0 && hh >= 0 && hh < cp.H && ww >= 0 && ww < cp.W && (!IN8 || tap < KT * 9);
             const long long r = rfr[j] + (long long)tt * HW + (long long)hh * cp.W + ww;
-            a_voff[j] = ok ? (unsigned)(r * cp.ldx * 2 + chunk_off) : CV_OOB;
+            a_voff[j] = ok ? (unsigned)(r * cp.ldx * 2 + (IN8 ? 0 : chunk_off)) : CV_OOB;
         }
     };
     int d_tap = 0, d_kc = 0;             // (tap, K-tile inside the tap) of the next K-tile to fetch
     auto dma = [&](int buf) {
         if (d_kc == 0) set_tap(d_tap);
-        const int a_soff = d_kc * CV_BK * 2;
-        const int w_soff = (d_tap * cp.Cin + d_kc * CV_BK) * 2;
+        const int a_soff = IN8 ? 0 : d_kc * CV_BK * 2;
+        const int w_soff = IN8 ? d_tap * CV_BK * 2 : (d_tap * cp.Cin + d_kc * CV_BK) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             char* dst = smem + buf * 32768 + (wv + 4 * j) * 1024;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = KT * 9 * kpt;
+    const int nk = IN8 ? (KT * 9 + 7) / 8 : KT * 9 * kpt;
     dma(0);
     __syncthreads();
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
@@ -214,4 +217,26 @@ extern "C" int vt_causal_conv3d_cl(const void* x, long long ldx, const void* wk,
 extern "C" int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const void* bias, void* y, long long ldy,
                                        int N, int T, int H, int W, int Cin, int Cout, void* stream) {
     return conv_launch<1, 2>(x, ldx, wk, bias, nullptr, 0, y, ldy, N, T, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+// The encoder's first convolution (RGB input): x bf16 [N,T,H,W,8] (8 channels per position, the unused ones zero), wk bf16
+// [Cout, 32 * 8] = the Conv3d weight [Cout, Cin<=8, 3,3,3] as (tap, channel) with taps 27..31 and channels >= Cin zero; y bf16
+// [N,T,H,W,Cout].  Same arithmetic as vt_causal_conv3d_cl with 8 taps per K-tile (4 K-tiles instead of 27).
+extern "C" int vt_causal_conv3d_in8_cl(const void* x, const void* wk, const void* bias, void* y, long long ldy,
+                                       int N, int T, int H, int W, int Cout, void* stream) {
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout % 4) || (ldy % 4) || ldy < Cout) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long rows = (long long)N * T * H * W;
+    const long long span = (5LL * H * W + ((long long)CV_BM / W + 4) * W + 256) * 16;
+    if (rows >= 0x7fffffffLL || span >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    Conv3dParams cp;
+    GemmParams& p = cp.g;
+    p.A = (const bf16_t*)x; p.W = (const bf16_t*)wk; p.C = y; p.bias = (const bf16_t*)bias;
+    p.R = nullptr; p.gate_txt = nullptr; p.gate_vid = nullptr; p.C2 = nullptr; p.U = nullptr;
+    p.M = (int)rows; p.N = Cout; p.K = 256; p.lda = 8; p.ldw = 256; p.ldc = (int)ldy; p.ldr = 0; p.ldc2 = 0; p.ldu = 0;
+    p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = 1;
+    cp.T = T; cp.H = H; cp.W = W; cp.Cin = 8; cp.Ho = H; cp.Wo = W; cp.ldx = 8; cp.x_rows = rows;
+    const int nbm = (p.M + CV_BM - 1) / CV_BM, nbn = (Cout + CV_BN - 1) / CV_BN;
+    hipLaunchKernelGGL((conv3d_cl_kernel<3, 1, EPI_BIAS, true>), dim3(nbm * nbn), dim3(256), 0, (hipStream_t)stream, cp);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

@@ -260,6 +260,28 @@ def causal_conv3d(x, wk, bias, y, residual=None):
     return y
 
 
+def pack_conv_in8_weight(w: torch.Tensor) -> torch.Tensor:
+    """Conv3d weight [Cout, Cin <= 8, 3, 3, 3] -> [Cout, 32 * 8]: (tap, channel), taps 27..31 and channels >= Cin zero"""
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3) or w.shape[1] > 8:
+        raise ValueError(f"expected a [Cout, Cin<=8, 3, 3, 3] weight, got {tuple(w.shape)}")
+    out = torch.zeros(w.shape[0], 32, 8, dtype=w.dtype, device=w.device)
+    out[:, :27, :w.shape[1]] = w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], 27, w.shape[1])
+    return out.reshape(w.shape[0], 256)
+
+
+def causal_conv3d_in8(x, wk, bias, y):
+    """first convolution of the VAE encoder: x bf16 [N,T,H,W,8] contiguous (RGB in channels 0..2), wk = pack_conv_in8_weight(w)"""
+    _req(x, BF16, "x", 5); _req(y, BF16, "y", 5); _req(wk, BF16, "wk", 2)
+    N, T, H, W, C8 = x.shape
+    Cout = y.shape[4]
+    if C8 != 8 or not x.is_contiguous() or tuple(y.shape[:4]) != (N, T, H, W) or tuple(wk.shape) != (Cout, 256) or not wk.is_contiguous():
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)} wk {tuple(wk.shape)} y {tuple(y.shape)}")
+    _cl_check(y, "y")
+    check(load_library().vt_causal_conv3d_in8_cl(x.data_ptr(), wk.data_ptr(), _p(bias), y.data_ptr(), y.stride(3), N, T, H, W, Cout,
+                                                 _stream()), "vt_causal_conv3d_in8_cl")
+    return y
+
+
 def downsample_conv2d(x, wk, bias, y):
     """per frame: zero line / column at the bottom / right, 3x3 conv, stride 2.  x bf16 [N,T,H,W,Cin], y bf16 [N,T,H/2,W/2,Cout]"""
     _req(x, BF16, "x", 5); _req(y, BF16, "y", 5); _req(wk, BF16, "wk", 2)

@@ -11,8 +11,8 @@ checked offline: no mapping is shipped yet.  Forward only (the VAE is frozen); t
 Layout: activations are channels-last ``[B, T, H, W, C]`` bf16 from the first convolution to the last -- the reference's
 ``b c t h w <-> (b t) c h w <-> (b h w) c t`` rearranges disappear.  Kernels: ``vt_causal_conv3d_cl`` (implicit-GEMM causal 3x3x3
 convolution, optional residual add), ``vt_groupnorm_silu_cl``, ``vt_gemm_bf16`` (the 1x1x1 shortcut), ``vt_temporal_pool_cl``,
-``vt_downsample_conv2d_cl``.  The RGB input (3 channels) is zero-padded to 64 channels for the first convolution (one K-tile per
-tap: 0.4 % of the encoder's FLOPs become 7 %).
+``vt_downsample_conv2d_cl``.  The RGB input is stored with 8 channels per position (one 16-byte chunk) and the first convolution
+(``vt_causal_conv3d_in8_cl``) packs 8 taps into a K-tile: 4 K-tiles instead of 27.
 """
 from __future__ import annotations
 
@@ -90,8 +90,8 @@ class CogVideoXVaeEncoder(nn.Module):
                  z_channels: int = 16, double_z: bool = True, temporal_compress_times: int = 4, scaling_factor: float = 1.15258426,
                  **unused):
         super().__init__()
-        if ch % 64 or in_channels > 64:
-            raise ValueError("ch must be a multiple of 64 (one K-tile of the convolution kernel) and in_channels <= 64")
+        if ch % 64 or in_channels > 8:
+            raise ValueError("ch must be a multiple of 64 (one K-tile of the convolution kernel) and in_channels <= 8")
         self.config = SimpleNamespace(ch=ch, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks, in_channels=in_channels,
                                       z_channels=z_channels, double_z=double_z, temporal_compress_times=temporal_compress_times,
                                       scaling_factor=scaling_factor)
@@ -147,10 +147,9 @@ class CogVideoXVaeEncoder(nn.Module):
             for name, m in self.named_modules():
                 if isinstance(m, _Conv) and m.weight.dim() >= 4:
                     w = m.weight
-                    if name == "conv_in.conv":                       # RGB -> 64 zero-padded input channels
-                        wp = torch.zeros(w.shape[0], 64, 3, 3, 3, dtype=w.dtype, device=w.device)
-                        wp[:, :w.shape[1]] = w
-                        w = wp
+                    if name == "conv_in.conv":                       # RGB: 8 channels per position, 8 taps per K-tile
+                        pk[name] = ops.pack_conv_in8_weight(w)
+                        continue
                     if w.dim() == 5 and tuple(w.shape[2:]) == (1, 1, 1):
                         pk[name] = w.reshape(w.shape[0], w.shape[1]).contiguous()
                     else:
@@ -190,10 +189,10 @@ class CogVideoXVaeEncoder(nn.Module):
         nlev = len(c.ch_mult)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError(f"H, W must be multiples of {1 << (nlev - 1)}")
-        xin = torch.zeros(B, T, H, W, 64, dtype=BF16, device=dev)                  # channels-last, RGB in the first 3 of 64 channels
+        xin = torch.zeros(B, T, H, W, 8, dtype=BF16, device=dev)                   # channels-last, RGB in the first 3 of 8 channels
         xin[..., :c.in_channels] = x.to(dev).permute(0, 2, 3, 4, 1)
         h = torch.empty(B, T, H, W, c.ch, dtype=BF16, device=dev)
-        ops.causal_conv3d(xin, pk["conv_in.conv"], self.conv_in.conv.bias, h)
+        ops.causal_conv3d_in8(xin, pk["conv_in.conv"], self.conv_in.conv.bias, h)
         del xin
         for i, lvl in enumerate(self.down):
             for j, blk in enumerate(lvl.block):

@@ -11,6 +11,7 @@
 // offset reads zeros) where the tap leaves the image.  No im2col buffer exists; each input row is fetched 27 times, from the L2
 // (a tile's halo is ~0.9 MB, shared with its neighbours on the same XCD).
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 struct Conv3dParams {
     GemmParams g;          // C = y, ldc, bias, R (residual), M = output positions, N = Cout (the epilogue's view); A / W = x / packed weight
@@ -176,6 +177,195 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Producer / consumer version (the structure of gemm_pc_bf16.hip: 256 x 128 tile, waves 0..3 multiply 128 x 64 each with
+// v_mfma_f32_32x32x16_bf16, waves 4..7 only issue LDS-DMA two K-tiles ahead in a three-stage ring, persistent over the output
+// tiles).  The address generation of the implicit GEMM -- decode of the output positions, per-tap validity and offsets -- runs in
+// the loader waves, which have nothing else to do, so the multipliers see an ordinary GEMM.
+#define CP_BM 256
+#define CP_STAGE 49152      // A 32 KiB | W 16 KiB
+#define CP_NS 3
+#define CP_PIECES 12        // LDS-DMA operations per loader wave and K-tile: 8 of A + 4 of W
+static __device__ __forceinline__ void cp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KT, int STRIDE, int EPI>
+__global__ __launch_bounds__(512, 1) void conv3d_pc_kernel(Conv3dParams cp) {
+    constexpr int PAD = STRIDE == 1 ? 1 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[CP_NS * CP_STAGE];
+    const GemmParams& p = cp.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbm = (p.M + CP_BM - 1) / CP_BM, nbn = (p.N + CV_BN - 1) / CV_BN;
+    const int ntiles = nbm * nbn;
+    const int spx = gridDim.x >> 3;
+    const int slot = (int)(blockIdx.x & 7) * spx + (int)(blockIdx.x >> 3);      // an XCD's slots are consecutive tiles: shared halos
+    const int kpt = cp.Cin / CV_BK;
+    const int nk = KT * 9 * kpt;                 // K-tiles per output tile
+    if (slot >= ntiles) return;
+    const int my_tiles = (ntiles - slot + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_kt = my_tiles * nk;
+    const int HW = cp.H * cp.W, HWo = cp.Ho * cp.Wo;
+
+    if (wave >= 4) {
+        // =================================== loader waves ===================================
+        const int lw = wave - 4;
+        const int drl = lane >> 3, dcp = lane & 7;
+        const int row0p = 8 * lw + drl;                       // this lane's row inside piece j: row0p + 32 j
+        const int chunk_off = (dcp ^ ((row0p >> 1) & 7)) << 4; // swz(row) = (row >> 1) & 7, unchanged by the 32-row piece step
+        const int w_voff0 = row0p * p.ldw * 2 + chunk_off;
+        const int w_pstep = 32 * p.ldw * 2;
+        int tile = slot;
+        int rt[8], rh[8], rw_[8];
+        long long rfr[8];
+        unsigned a_voff[8];
+        __amdgpu_buffer_rsrc_t ra, rw;
+        auto set_tile = [&](int tl) {
+            const int row0 = (tl / nbn) * CP_BM, col0 = (tl % nbn) * CV_BN;
+            const long long nt0 = (long long)row0 / HWo;
+            int tt = (int)(nt0 % cp.T) - (KT - 1); tt = tt < 0 ? 0 : tt;
+            const long long base_row = ((nt0 / cp.T) * cp.T + tt) * (long long)HW;         // first frame the tile can touch
+            const long long a_rem = (cp.x_rows - base_row) * cp.ldx * 2;
+            ra = make_rsrc(p.A + base_row * cp.ldx, (unsigned)(a_rem > 0x7fffffffLL ? 0x7fffffffLL : a_rem));
+            const long long w_rem = (long long)(p.N - col0) * p.ldw * 2;
+            rw = make_rsrc(p.W + (size_t)col0 * p.ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long m = (long long)row0 + row0p + 32 * j;
+                if (m < p.M) {
+                    const int sp = (int)(m % HWo);
+                    const long long nt = m / HWo;
+                    rt[j] = (int)(nt % cp.T);
+                    rh[j] = sp / cp.Wo;
+                    rw_[j] = sp - rh[j] * cp.Wo;
+                    rfr[j] = (nt / cp.T) * cp.T * (long long)HW - base_row;
+                } else {
+                    rt[j] = -1; rh[j] = 0; rw_[j] = 0; rfr[j] = 0;
+                }
+            }
+        };
+        auto set_tap = [&](int tap) {
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int tt = rt[j] + dt - (KT - 1);
+                tt = tt < 0 ? 0 : tt;
+                const int hh = rh[j] * STRIDE + dh - PAD, ww = rw_[j] * STRIDE + dw - PAD;
+                const bool ok = rt[j] >= 0 && hh >= 0 && hh < cp.H && ww >= 0 && ww < cp.W;
+                const long long r = rfr[j] + (long long)tt * HW + (long long)hh * cp.W + ww;
+                a_voff[j] = ok ? (unsigned)(r * cp.ldx * 2 + chunk_off) : CV_OOB;
+            }
+        };
+        set_tile(tile);
+        int d_tap = 0, d_kc = 0;
+        auto issue = [&](int g) {                // K-tile number g of the stream -> stage g % 3
+            if (d_kc == 0) set_tap(d_tap);
+            const int a_soff = d_kc * CV_BK * 2;
+            const int w_soff = (d_tap * cp.Cin + d_kc * CV_BK) * 2;
+            char* st = smem + (g % CP_NS) * CP_STAGE + lw * 1024;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(st + j * 4096), 16, (int)a_voff[j], a_soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(st + 32768 + j * 4096), 16, w_voff0, w_soff + j * w_pstep, 0, 0);
+            if (++d_kc == kpt) {
+                d_kc = 0;
+                if (++d_tap == KT * 9) {         // next K-tile belongs to the next output tile
+                    d_tap = 0;
+                    tile += gridDim.x;
+                    if (tile < ntiles) set_tile(tile);
+                }
+            }
+        };
+        int issued = 0;
+        for (; issued < 2 && issued < total_kt; ++issued) issue(issued);
+        for (int g = 0; g < total_kt; ++g) {
+            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CP_PIECES) : "memory");     // K-tile g landed, g+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            cp_barrier();                        // (A) stage g % 3 is ready / stage (g-1) % 3 has been consumed
+            if ((g + 1) % nk == 0) {
+#pragma unroll 1
+                for (int i = 0; i < 17; ++i) cp_barrier();      // mirror the multipliers' epilogue barriers
+            }
+            if (issued < total_kt) { issue(issued); ++issued; }
+        }
+        return;
+    }
+
+    // =================================== multiplier waves (an ordinary GEMM from here on) ===================================
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fh = lane >> 5, fx = (fr >> 1) & 7;
+    const int er = tid >> 5, ec = (tid & 31) * 4;
+    int g = 0;
+    for (int tile = slot; tile < ntiles; tile += gridDim.x) {
+        const int row0 = (tile / nbn) * CP_BM, col0 = (tile % nbn) * CV_BN;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            cp_barrier();                    // (A) the loaders have landed stage g % 3
+            const char* As = smem + (g % CP_NS) * CP_STAGE + (wm * 128 + fr) * 128;
+            const char* Ws = smem + (g % CP_NS) * CP_STAGE + 32768 + (wn * 64 + fr) * 128;
+            bf16x8 af[2][4], wf[2][2];
+            auto frags = [&](int ks) {
+                const int coff = (((ks * 2 + fh) ^ fx) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) af[ks & 1][t] = *(const bf16x8*)(As + t * 4096 + coff);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[ks & 1][t] = *(const bf16x8*)(Ws + t * 4096 + coff);
+            };
+            frags(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) frags(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][tn], af[ks & 1][tm], acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---------------- epilogue: eight 32-row slabs through the stage that was just consumed (17 barriers) ----------------
+        float* Cs = (float*)(smem + ((g - 1) % CP_NS) * CP_STAGE);
+        const int n = col0 + ec;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n < p.N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+        }
+        cp_barrier();
+#pragma unroll
+        for (int slab = 0; slab < 8; ++slab) {
+            if (wm == (slab >> 2)) {
+                const int tm = slab & 3;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(f32x4*)(Cs + fr * CV_CS_LD + wn * 64 + tn * 32 + 8 * q + 4 * fh) =
+                            (f32x4){acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+            }
+            cp_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int ml = pass * 8 + er;
+                const int m = row0 + slab * 32 + ml;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = *(const f32x4*)(Cs + ml * CV_CS_LD + ec);
+                    gemm_epilogue_store<EPI, false>(p, m, n, v, bias4);
+                }
+            }
+            cp_barrier();
+        }
+    }
+}
+
 template <int KT, int STRIDE>
 static int conv_launch(const void* x, long long ldx, const void* wk, const void* bias, const void* res, long long ldr, void* y, long long ldy,
                        int N, int T, int H, int W, int Cin, int Cout, hipStream_t st) {
@@ -196,7 +386,29 @@ static int conv_launch(const void* x, long long ldx, const void* wk, const void*
     p.M = (int)rows_out; p.N = Cout; p.K = KT * 9 * Cin; p.lda = (int)ldx; p.ldw = KT * 9 * Cin; p.ldc = (int)ldy; p.ldr = (int)ldr;
     p.ldc2 = 0; p.ldu = 0; p.S = 1; p.St = 0; p.gate_bstride = 0; p.r_mod = 0; p.splits = 1;
     cp.T = T; cp.H = H; cp.W = W; cp.Cin = Cin; cp.Ho = Ho; cp.Wo = Wo; cp.ldx = ldx; cp.x_rows = rows_in;
-    const int nbm = (p.M + CV_BM - 1) / CV_BM, nbn = (Cout + CV_BN - 1) / CV_BN;
+    // kernel: the producer / consumer one (256-row tiles, persistent) where it was measured faster; VT_CONV_KERNEL=1|2 forces the
+    // 128-row / the producer-consumer kernel
+    static int kmode = -1, slots = 0;
+    if (kmode < 0) {
+        const char* e = getenv("VT_CONV_KERNEL");
+        kmode = e ? atoi(e) : 0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        slots = cus >= 8 ? cus / 8 * 8 : 8;
+    }
+    const int nbn = (Cout + CV_BN - 1) / CV_BN;
+    const long long tiles_pc = ((rows_out + CP_BM - 1) / CP_BM) * nbn;
+    const long long span_pc = ((long long)(KT + 2) * H * W + ((long long)CP_BM / Wo + 4) * STRIDE * W + 256) * ldx * 2;
+    // measured (tools/kbench.py conv, VT_CONV_KERNEL=1 / 2): 128 -> 128 at 480x720 822 / 804 TFLOP/s, 256 -> 256 at 240x360 1024 / 1087,
+    // at 120x180 1055 / 1048, 512 -> 512 at 60x90 1117 / 1065: the 256-row kernel pays only with two column tiles and many rounds
+    const bool pc = span_pc < 0x7fffffffLL && (kmode == 2 || (kmode == 0 && nbn >= 2 && tiles_pc >= 16LL * slots));
+    if (pc) {
+        const int grid = tiles_pc < slots ? (int)((tiles_pc + 7) / 8 * 8) : slots;
+        if (res != nullptr) hipLaunchKernelGGL((conv3d_pc_kernel<KT, STRIDE, EPI_GATED_RES>), dim3(grid), dim3(512), 0, st, cp);
+        else hipLaunchKernelGGL((conv3d_pc_kernel<KT, STRIDE, EPI_BIAS>), dim3(grid), dim3(512), 0, st, cp);
+        return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+    }
+    const int nbm = (p.M + CV_BM - 1) / CV_BM;
     if (res != nullptr) hipLaunchKernelGGL((conv3d_cl_kernel<KT, STRIDE, EPI_GATED_RES>), dim3(nbm * nbn), dim3(256), 0, st, cp);
     else hipLaunchKernelGGL((conv3d_cl_kernel<KT, STRIDE, EPI_BIAS>), dim3(nbm * nbn), dim3(256), 0, st, cp);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;

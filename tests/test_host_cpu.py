@@ -346,6 +346,18 @@ def test_vae_encoder_host_side():
         assert tuple(got[k].shape) == tuple(v.shape), k
     m.load_state_dict(want)
     assert abs(m.config.scaling_factor - 1.15258426) < 1e-9
+    # a whole-autoencoder checkpoint of the twin: encoder sub-tree taken, the rest ignored; safetensors file round trip
+    import tempfile
+    from safetensors.torch import save_file
+    full_ckpt = {"first_stage_model.encoder." + k: v for k, v in want.items()}
+    full_ckpt["first_stage_model.decoder.conv_in.conv.weight"] = torch.zeros(3)
+    m.load_state_dict(full_ckpt)
+    with tempfile.TemporaryDirectory() as d:
+        save_file({"encoder." + k: v.contiguous() for k, v in want.items()}, os.path.join(d, "model.safetensors"))
+        m3 = CogVideoXVaeEncoder.from_pretrained(d, ch=cfg.ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks,
+                                                 z_channels=cfg.z_channels, temporal_compress_times=cfg.temporal_compress_times)
+    for k, v in want.items():
+        assert torch.equal(m3.state_dict()[k], v.to(torch.bfloat16)), k
     d = DiagonalGaussianDistribution(torch.zeros(1, 8, 2, 3, 3))
     assert tuple(d.sample().shape) == (1, 4, 2, 3, 3) and torch.equal(d.mode(), torch.zeros(1, 4, 2, 3, 3))
     full = CogVideoXVaeEncoder()

@@ -114,9 +114,33 @@ class CogVideoXVaeEncoder(nn.Module):
         self._packed = None
 
     # ------------------------------------------------------------------ weights
+    _PREFIXES = ("first_stage_model.encoder.", "encoder.")      # full SAT / autoencoder checkpoints carry the encoder under these
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """accepts the encoder's own keys or a whole autoencoder checkpoint of the in-tree twin (its ``encoder.`` sub-tree is taken,
+        decoder / loss keys are ignored)"""
         self._packed = None
-        return super().load_state_dict({k: v.to(BF16) for k, v in state_dict.items()}, strict=strict, **kw)
+        sd = dict(state_dict)
+        for pre in self._PREFIXES:
+            if any(k.startswith(pre) for k in sd):
+                sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+                break
+        return super().load_state_dict({k: v.to(BF16) for k, v in sd.items()}, strict=strict, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, **config):
+        """``path``: a .safetensors file (or a directory holding ``model.safetensors`` / ``diffusion_pytorch_model.safetensors``) with
+        the in-tree twin's parameter names; ``config`` overrides the CogVideoX defaults.  Nothing is fetched."""
+        import os
+        from safetensors.torch import load_file
+        if os.path.isdir(path):
+            for fn in ("model.safetensors", "diffusion_pytorch_model.safetensors"):
+                if os.path.exists(os.path.join(path, fn)):
+                    path = os.path.join(path, fn)
+                    break
+        model = cls(**config)
+        model.load_state_dict(load_file(path))
+        return model
 
     def init_weights(self, seed: int = 0):
         g = torch.Generator().manual_seed(seed)

@@ -176,3 +176,19 @@ def test_t5_xxl_layer_fullsize(dev):
     out3 = m(ids.to(dev))[0]
     err3 = (out3.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
     assert err3 < 3e-2, err3
+
+
+def test_causal_conv3d_fullsize_geometry(dev):
+    """The VAE encoder's first block at its real frame geometry (480 x 720, 128 -> 128 channels, 3 frames: every temporal tap of the
+    last frame reaches a frame 88 MB away, lines are 184 KB apart): implicit-GEMM kernel vs fp32 F.conv3d on the host, all outputs."""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(12)
+    T, H, W, C = 3, 480, 720, 128
+    x = rb(torch.randn(1, T, H, W, C, generator=g))
+    w = rb(torch.randn(C, C, 3, 3, 3, generator=g) * (1.0 / (27 * C) ** 0.5)); b = rb(torch.randn(C, generator=g))
+    xin = x.permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(torch.cat([xin[:, :, :1]] * 2 + [xin], dim=2), w, b, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+    y = torch.empty(1, T, H, W, C, dtype=BF, device=dev)
+    ops.causal_conv3d(x.to(dev, BF), ops.pack_conv_weight(w).to(dev, BF), b.to(dev, BF), y)
+    rel, mx = relerr(y, ref)
+    assert rel < 5e-3 and mx < 2e-2, (rel, mx)

@@ -192,3 +192,20 @@ def test_causal_conv3d_fullsize_geometry(dev):
     ops.causal_conv3d(x.to(dev, BF), ops.pack_conv_weight(w).to(dev, BF), b.to(dev, BF), y)
     rel, mx = relerr(y, ref)
     assert rel < 5e-3 and mx < 2e-2, (rel, mx)
+
+
+def test_vae_encoder_real_configuration(dev):
+    """The CogVideoX encoder at its REAL configuration (ch 128, ch_mult (1,2,2,4), 3 ResNet blocks per level, 16 latent channels,
+    4x temporal / 8x spatial compression; 53 M parameters, seeded) on a small 9 x 64 x 96 clip against the fp32 oracle."""
+    import vae_oracle as V
+    from vt355.vae import CogVideoXVaeEncoder
+    cfg = V.VaeEncConfig()
+    m = CogVideoXVaeEncoder().init_weights(6).to(dev)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    x = torch.randn(1, 3, 9, 64, 96, generator=torch.Generator().manual_seed(2)).clamp(-1, 1).to(BF)
+    out = m(x.to(dev))
+    ref = V.encoder_forward(P, cfg, x.float())
+    assert tuple(out.shape) == tuple(ref.shape) == (1, 32, 3, 8, 12)
+    rel, mx = relerr(out, ref)
+    cos = F.cosine_similarity(out.float().cpu().reshape(-1), ref.reshape(-1), dim=0).item()
+    assert mx < 5e-2 and cos > 0.999, (rel, mx, cos)

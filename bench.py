@@ -18,6 +18,51 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves, one process per GPU as PL's
+    DDPStrategy does (videotuna/utils/train_utils.py:127-139, scripts/train.py:215-217).  Runs BEFORE this process
+    imports torch or touches the GPU (children are fresh interpreters, nothing is exec'ed over a process that holds a
+    device); rank 0's stdout is this process's stdout, so its JSON line is the output.  Non-zero when any rank fails;
+    the remaining ranks are then terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def _wants_launch(argv):
+    """--gpus N > 1 with no rendezvous environment around us -> we are the launcher"""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    return n if (n > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ) else 0
+
+
+if __name__ == "__main__" and _wants_launch(sys.argv[1:]):
+    sys.exit(launch_ranks(_wants_launch(sys.argv[1:]), sys.argv[1:]))
+
 import torch
 import torch.distributed as dist
 
@@ -67,7 +112,26 @@ def main():
                          "(cogvideo_pl.py:792-813); default: pre-encoded latents")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU work: the ranks only rendezvous (gloo), all-reduce one number and rank 0 prints it -- the CPU test "
+                         "of the launcher / rank plumbing (tests/test_ddp_cpu.py)")
     args = ap.parse_args()
+
+    if args.rehearse:
+        from vt355.ddp import init_from_env
+        if os.environ.get("VT_REHEARSE_FAIL_RANK") == os.environ.get("RANK", "0"):
+            sys.exit(3)                          # test hook: a rank that dies before the rendezvous
+        rank, local, world = init_from_env("gloo")
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        tt = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(tt)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "rank_sum": tt.item(), "local_rank": local}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from vt355 import ops
     from vt355.ddp import BucketedReducer, FlatGradReducer, broadcast_flat, init_from_env
@@ -148,6 +212,9 @@ def main():
                     p.zero_()
         if side is None:
             side = torch.cuda.Stream(device=dev)
+
+    if side is not None:
+        ops.declare_side_stream(True)       # encoder kernels share the CUs with the backward: no dQ hand-off chains (plain atomics)
 
     def make_batch():
         if vae is not None:                             # raw clips -> frozen VAE encoder on the side stream, sample by sample

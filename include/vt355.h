@@ -13,7 +13,14 @@
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no hidden syncs,
  *     no allocation, no host reads of device data -> safe under hipGraph capture;
  *   - return 0 on success, a negative VT_ERR_* otherwise; no C++ exception crosses the ABI;
- *   - reentrant and stateless: safe from autograd's backward thread; one process per GPU.
+ *   - compute entry points keep no state between calls and are safe from autograd's backward thread (one process per
+ *     GPU, as PL's DDPStrategy runs the reference).  Two process-global TUNING knobs exist for tests and A/B timing only --
+ *     vt_gemm_set_tile, vt_attn_bwd_set_chain (and the VT_* environment variables read once at first use);
+ *     they select between kernels that give the same results, the product path never calls them.
+ *   - deviation from SURVEY 8(b)'s sketch of this ABI (vt_tensor descriptors, vt_<op>_params structs,
+ *     vt_workspace_bytes_<op>, vt_last_error): arguments are flat pointers + leading dimensions (one ctypes call, no struct
+ *     marshalling), workspaces are sized by vt_<op>_ws_bytes / vt_<op>_workspace_bytes where an op needs one, errors are the
+ *     return code + vt_error_string(code) (no thread-local last-error state).  Listed in DESIGN.md 4.
  */
 #ifndef VT355_H
 #define VT355_H
@@ -27,7 +34,7 @@ extern "C" {
 #define VT_ERR_LAUNCH (-3)
 #define VT_ERR_UNSUPPORTED (-4)
 
-int vt_version(void);                 /* ABI version, currently 1 */
+int vt_version(void);                 /* ABI version, currently 2 (r02: vt_adamw guard, vt_temporal_pool_cl keep_first, UNet entry points) */
 const char* vt_arch(void);            /* "gfx950" */
 const char* vt_error_string(int code);
 
@@ -135,9 +142,12 @@ int vt_downsample_conv2d_cl(const void* x, long long ldx, const void* wk, const 
  * the Conv3d weight as (tap, channel) with taps 27..31 and channels >= Cin zero; 8 taps per K-tile instead of one. */
 int vt_causal_conv3d_in8_cl(const void* x, const void* wk, const void* bias, void* y, long long ldy,
                             int N, int T, int H, int W, int Cout, void* stream);
-/* Temporal compression of the VAE's DownSample3D (cp_enc_dec.py:640-657): frame 0 kept, frames 1.. averaged in consecutive pairs
- * (a trailing odd frame is dropped): x bf16 [N,T,HW,C] -> y bf16 [N, 1 + (T-1)/2, HW, C], channels-last. */
-int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, void* stream);
+/* Temporal compression of the VAE's DownSample3D (cp_enc_dec.py:640-667).  keep_first != 0 (its rank-0 / fake_cp branch, :645-657, and
+ * diffusers' CogVideoXDownsample3D for an ODD frame count): frame 0 kept, frames 1.. averaged in consecutive pairs (a trailing odd
+ * frame is dropped): x bf16 [N,T,HW,C] -> y bf16 [N, 1 + (T-1)/2, HW, C].  keep_first == 0 (its other branch, :658-667, and diffusers
+ * for an EVEN frame count): avg_pool1d(2, 2) over all frames, y bf16 [N, T/2, HW, C].  Channels-last. */
+int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, int keep_first,
+                        void* stream);
 /* T5LayerNorm: y[m,:] = x[m,:] * rsqrt(mean(x[m,:]^2) + eps) * w  (bf16 rows of D, fp32 statistics; no mean, no bias) */
 int vt_rmsnorm_bf16(const void* x, long long ldx, const void* w, void* y, long long ldy, long long M, int D, float eps,
                     void* stream);
@@ -147,9 +157,12 @@ int vt_gated_gelu_bf16(const void* u, long long ldu, void* y, long long ldy, lon
 /* Flash attention backward.  delta_ws: [B*H*S] fp32 workspace; dq_f32: fp32 [.., H*64] accumulation buffer
  * that the CALLER ZEROES beforehand (dQ is summed across key blocks with fp32 atomics); dk, dv bf16.
  * chain_ws / chain_ws_bytes: optional scratch (256-byte aligned, >= vt_attn_bwd_chain_ws_bytes(B,H,S) bytes, contents
- * don't matter) that lets runs of consecutive key blocks hand their running dQ tile to each other so that only one
- * block per run issues atomics (csrc/attn_bwd.hip); NULL: every key block adds atomically.  ((int*)chain_ws)[8] is
- * an error word: non-zero after the launch if a hand-off wait timed out (dQ is then invalid).
+ * of bytes >= 256 don't matter) that lets runs of consecutive key blocks hand their running dQ tile to each other so that
+ * only one block per run issues atomics (csrc/attn_bwd.hip); NULL: every key block adds atomically.  ((int*)chain_ws)[8] is
+ * the error word of THIS launch: non-zero if a hand-off wait timed out (dQ is then invalid).  ((int*)chain_ws)[16] is
+ * STICKY: it counts time-outs over all launches and is never cleared by the library -- the caller zeroes bytes [64, 256)
+ * once when it allocates the workspace and hands &((int*)chain_ws)[16] to vt_adamw as `guard`, so that an optimizer step
+ * whose gradients came from an invalid launch is refused on the device.
  * Replaces: autograd of the SDPA call above (loss.backward() under PL). */
 int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o, const void* dout,
                      const float* lse2, float* delta_ws, float* dq_f32, void* dk, void* dv,
@@ -220,9 +233,10 @@ int vt_diffusion_loss_bwd(const void* vpred, const void* noisy, const float* x0,
                           long long per_sample, int B, void* stream);
 
 /* torch.optim.AdamW step (cogvideo_pl.py:774-779) over one flat fp32 buffer; g is multiplied by grad_scale
- * first; p_bf16 (optional) receives the bf16 compute copy. step is 1-based. */
+ * first; p_bf16 (optional) receives the bf16 compute copy. step is 1-based.  guard (optional, device int): when *guard != 0
+ * at execution time the whole update is skipped (p, m, v untouched) -- the sticky error word of vt_attn_bwd_hd64. */
 int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
-             float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+             float beta2, float eps, float weight_decay, int step, float grad_scale, const int* guard, void* stream);
 
 /* LoRA (peft LoraLayer, cogvideo_pl.py:143-149) */
 int vt_lora_down(const void* X, int ldx, const void* A, int lda, int R, void* T, int ldt, long long M, int K,

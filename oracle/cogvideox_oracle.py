@@ -345,6 +345,23 @@ def dit_block(h_txt, h_vid, emb, P, prefix, cfg: DiTConfig, lora=None, lora_scal
     return h_txt, h_vid
 
 
+def dit_final(h_vid, emb, P, cfg: DiTConfig, Fr: int, Hh: int, Ww: int):
+    """norm_final (video tokens only for 2B) -> AdaLayerNorm(chunk order shift, scale) -> proj_out -> unpatchify (c p q).
+    In-tree twin: FinalLayerMixin.final_forward, cogvideo_sat/dit_video_concat.py:478-498 (one LayerNorm there; diffusers has
+    norm_final AND norm_out.norm) -- pinned by tests/golden/sat_dit_block.npz."""
+    B = h_vid.shape[0]
+    p, d = cfg.patch_size, cfg.inner_dim
+    h = F.layer_norm(h_vid, (d,), P["norm_final.weight"], P["norm_final.bias"], cfg.norm_eps)
+    mod = F.linear(F.silu(emb), P["norm_out.linear.weight"], P["norm_out.linear.bias"])
+    shift, scale = mod.chunk(2, dim=1)
+    h = F.layer_norm(h, (d,), P["norm_out.norm.weight"], P["norm_out.norm.bias"], cfg.norm_eps)
+    h = h * (1 + scale)[:, None] + shift[:, None]
+    h = F.linear(h, P["proj_out.weight"], P["proj_out.bias"])       # [B, Sv, C*p*p] in (c p q) order
+    out = h.reshape(B, Fr, Hh // p, Ww // p, -1, p, p)
+    out = out.permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    return out
+
+
 def dit_forward(P: Dict[str, torch.Tensor], cfg: DiTConfig, hidden_states: torch.Tensor,
                 encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
                 lora: Optional[Dict[str, torch.Tensor]] = None, lora_scale: float = 0.25,
@@ -384,17 +401,8 @@ def dit_forward(P: Dict[str, torch.Tensor], cfg: DiTConfig, hidden_states: torch
                                  rope=image_rotary_emb)
         if taps is not None:
             taps[f"block{i}_txt"], taps[f"block{i}_vid"] = h_txt, h_vid
-    # 4. final: LN (video tokens only for 2B) -> AdaLayerNorm(shift, scale) -> proj
-    h = F.layer_norm(h_vid, (d,), P["norm_final.weight"], P["norm_final.bias"], cfg.norm_eps)
-    mod = F.linear(F.silu(emb), P["norm_out.linear.weight"], P["norm_out.linear.bias"])
-    shift, scale = mod.chunk(2, dim=1)
-    h = F.layer_norm(h, (d,), P["norm_out.norm.weight"], P["norm_out.norm.bias"], cfg.norm_eps)
-    h = h * (1 + scale)[:, None] + shift[:, None]
-    h = F.linear(h, P["proj_out.weight"], P["proj_out.bias"])       # [B, Sv, C*p*p] in (c p q) order
-    # 5. unpatchify
-    out = h.reshape(B, Fr, Hh // p, Ww // p, -1, p, p)
-    out = out.permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
-    return out
+    # 4./5. final layers + unpatchify
+    return dit_final(h_vid, emb, P, cfg, Fr, Hh, Ww)
 
 
 # --------------------------------------------------------------------------------------

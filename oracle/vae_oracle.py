@@ -70,16 +70,23 @@ def resnet_block(x, P, pre, cin, cout):
     return x + h
 
 
-def downsample(x, P, pre, compress_time):
+def downsample(x, P, pre, compress_time, keep_first=None):
+    """DownSample3D.forward (cp_enc_dec.py:640-676).  keep_first None: diffusers' rule (CogVideoXDownsample3D) -- odd frame count:
+    the twin's rank-0 / fake_cp branch (:645-657, first frame kept, pairs after it); even: its other branch (:658-667, plain pairs)."""
     B, C, T, H, W = x.shape
     if compress_time and T > 1:
         xt = x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, T)
-        first, rest = xt[..., :1], xt[..., 1:]
-        if rest.shape[-1] > 1:
-            rest = F.avg_pool1d(rest, kernel_size=2, stride=2)
+        if keep_first is None:
+            keep_first = (T % 2 == 1)
+        if keep_first:
+            first, rest = xt[..., :1], xt[..., 1:]
+            if rest.shape[-1] > 1:
+                rest = F.avg_pool1d(rest, kernel_size=2, stride=2)
+            else:
+                rest = rest[..., :0]
+            xt = torch.cat([first, rest], dim=-1)
         else:
-            rest = rest[..., :0]
-        xt = torch.cat([first, rest], dim=-1)
+            xt = F.avg_pool1d(xt, kernel_size=2, stride=2)
         T = xt.shape[-1]
         x = xt.reshape(B, H, W, C, T).permute(0, 3, 4, 1, 2)
     x = F.pad(x, (0, 1, 0, 1))

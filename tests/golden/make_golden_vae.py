@@ -53,6 +53,22 @@ def main():
         out = enc(x)
     np.savez_compressed(os.path.join(HERE, "vae_encoder_tiny.npz"), x=x.numpy(), out=out.numpy(), **{"P." + k: v.numpy() for k, v in P.items()})
     print("wrote vae_encoder_tiny.npz", tuple(out.shape), float(out.abs().max()))
+    # DownSample3D alone, both temporal branches (cp_enc_dec.py:640-676): rank-0 / fake_cp (first frame kept) and the plain
+    # avg_pool1d branch (fake_cp=False), on an odd and an even frame count
+    ds = mod.DownSample3D(32, with_conv=True, compress_time=True).eval()
+    gd = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for p_ in ds.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=gd) * 0.1)
+    rec = {"ds.conv.weight": ds.conv.weight.detach().numpy(), "ds.conv.bias": ds.conv.bias.detach().numpy()}
+    for T in (9, 8, 4):
+        xd = torch.randn(1, 32, T, 6, 8, generator=gd)
+        rec[f"x{T}"] = xd.numpy()
+        with torch.no_grad():
+            rec[f"keep_first{T}"] = ds(xd, fake_cp=True).numpy()
+            rec[f"all_pairs{T}"] = ds(xd, fake_cp=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "vae_downsample3d.npz"), **rec)
+    print("wrote vae_downsample3d.npz", {k: v.shape for k, v in rec.items()})
     dist.destroy_process_group()
 
 

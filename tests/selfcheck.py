@@ -1,5 +1,6 @@
 """One tiny end-to-end training step of the hot path on cuda:0, checked against the CPU oracle.
-Used by ``__graft_entry__.smoke()`` and by the GPU parity tests (the oracle is the checker, never the product)."""
+Test infrastructure (lives under tests/, imports oracle/): used by ``__graft_entry__.smoke()`` and by the GPU parity tests --
+the oracle is the checker, never the product; the package ``videotuna-dev_amd`` imports nothing from here."""
 from __future__ import annotations
 
 import torch
@@ -12,8 +13,8 @@ CFG_KEYS = ("num_attention_heads", "attention_head_dim", "in_channels", "out_cha
 
 def build_tiny(device, layers=2, heads=2, seed=0, lora_b_random=True, **cfg_kw):
     import cogvideox_oracle as O
-    from .dit import CogVideoXTransformer3DModel
-    from .lora import LoraConfig, get_peft_model
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.lora import LoraConfig, get_peft_model
     cfg = O.tiny_config(num_layers=layers, num_attention_heads=heads, **cfg_kw)
     kw = {k: getattr(cfg, k) for k in CFG_KEYS}
     model = CogVideoXTransformer3DModel(**kw).init_weights(seed).to(device)
@@ -47,9 +48,9 @@ def oracle_params(model, st, dtype=torch.float32):
 
 def tiny_train_step_check(verbose=False, B=2, tol_loss=2e-2, tol_grad=6e-2, rope=False):
     import cogvideox_oracle as O
-    from .scheduler import CogVideoXDPMScheduler
-    from .workflow import _LossFn
-    from .optim import FusedAdamW
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.workflow import _LossFn
+    from vt355.optim import FusedAdamW
     dev = torch.device("cuda:0")
     cfg, model, peft, st = build_tiny(dev, use_rotary_positional_embeddings=rope)
     g = torch.Generator().manual_seed(123)

@@ -66,3 +66,30 @@ def test_bucketed_reducer_world2():
     mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     for r in (0, 1):
         assert out[r] == (1000, True, 0.5)
+
+
+def _bench(*argv, **env):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no torchrun around it starts N ranks itself (one process per GPU, the reference's
+    DDPStrategy shape) and relays rank 0's JSON line; --rehearse keeps the GPU out of it"""
+    rc, line = _bench("--gpus", "2", "--rehearse")
+    assert rc == 0 and line == {"rehearsal": True, "n_gpus": 2, "rank_sum": 3.0, "local_rank": 0}
+
+
+def test_bench_under_an_external_launcher_does_not_relaunch():
+    rc, line = _bench("--gpus", "1", "--rehearse", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    assert rc == 0 and line["n_gpus"] == 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    rc, line = _bench("--gpus", "2", "--rehearse", VT_REHEARSE_FAIL_RANK="1")
+    assert rc != 0 and line is None

@@ -102,7 +102,7 @@ def test_one_full_size_block_train_step(dev, family):
     from vt355.lora import LoraConfig, get_peft_model
     from vt355.rope import prepare_rotary_positional_embeddings
     from vt355.scheduler import CogVideoXDPMScheduler
-    from vt355.selfcheck import oracle_params
+    from selfcheck import oracle_params
     from vt355.workflow import _LossFn
     kw = dict(num_layers=1) if family == "2b" else dict(num_layers=1, num_attention_heads=48, use_rotary_positional_embeddings=True)
     cfg = O.DiTConfig(**kw)

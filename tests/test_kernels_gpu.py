@@ -175,6 +175,63 @@ def test_attn_bwd(dev, B, S, H, spike, pre, chain):
     close(dv.view(B, S, H, 64), dref[:, :, 2], 3e-2, 1e-2 * scale, "dv")
 
 
+def test_attn_bwd_timeout_is_sticky_and_the_optimizer_refuses_the_step(dev):
+    """libvt355_test.so holds the attention backward built with CH_SPIN_LIMIT=0: every dQ hand-off wait that is not
+    satisfied at once gives up.  The per-launch error word is set, the STICKY counter keeps it after a later clean launch
+    of the shipped kernel on the same workspace, vt_adamw leaves parameters / moments untouched while the counter is
+    non-zero, and FusedAdamW raises at the next step."""
+    import ctypes as C
+    import os
+    from vt355 import ops, _lib
+    from vt355.optim import FusedAdamW
+    tpath = os.path.join(os.path.dirname(_lib.lib_path()), "libvt355_test.so")
+    assert os.path.exists(tpath), "libvt355_test.so missing: run __graft_entry__.build()"
+    _lib.load_library()
+    tlib = C.CDLL(tpath)
+    fn = tlib.vt_attn_bwd_hd64_tmo
+    fn.argtypes = _lib.PROTOTYPES["vt_attn_bwd_hd64"]; fn.restype = C.c_int
+    B, S, H = 1, 3000, 2
+    D = H * 64
+    g = torch.Generator().manual_seed(5)
+    d = rb(torch.randn(B, S, 3 * D, generator=g)).to(dev, BF)
+    qd, kd, vd = d[:, :, :D], d[:, :, D:2 * D], d[:, :, 2 * D:]
+    o = torch.empty(B, S, D, dtype=BF, device=dev); lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attn_fwd(qd, kd, vd, o, lse2, B, H, S)
+    do = rb(torch.randn(B, S, D, generator=g)).to(dev, BF)
+    dq = torch.zeros(B, S, D, dtype=torch.float32, device=dev)
+    dk = torch.empty(B, S, D, dtype=BF, device=dev); dv = torch.empty(B, S, D, dtype=BF, device=dev)
+    delta = torch.empty(B * H * S, dtype=torch.float32, device=dev)
+    ws = ops.attn_bwd_chain_workspace(B, H, S, dev)
+    assert ws is not None
+    ops.attn_bwd_chain_errors_clear()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = fn(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), do.data_ptr(), lse2.data_ptr(), delta.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S,
+            qd.stride(1), kd.stride(1), vd.stride(1), o.stride(1), do.stride(1), dq.stride(1), dk.stride(1), dv.stride(1),
+            qd.stride(0), kd.stride(0), vd.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
+            0.125, 0, ws.data_ptr(), ws.numel(), st)
+    assert rc == 0
+    assert ops.attn_bwd_chain_error(ws) != 0, "the CH_SPIN_LIMIT=0 build did not time out"
+    try:
+        # a later clean launch clears the per-launch word but not the sticky count
+        dq.zero_()
+        ops.attn_bwd(qd, kd, vd, o, do, lse2, delta, dq, dk, dv, B, H, S, chain_ws=ws)
+        assert ops.attn_bwd_chain_error(ws) == 0
+        assert ops.attn_bwd_chain_errors() > 0
+        # the optimizer refuses the update on the device and raises at the next step
+        p = torch.nn.Parameter(torch.ones(1000, device=dev)); p.grad = torch.ones(1000, device=dev)
+        opt = FusedAdamW([p], lr=0.1)
+        opt.step()
+        assert torch.all(p.detach() == 1.0) and torch.all(opt.m[0] == 0.0), "vt_adamw ran although the guard was set"
+        with pytest.raises(_lib.VtError, match="timed out"):
+            opt.step()
+    finally:
+        ops.attn_bwd_chain_errors_clear()
+    opt2 = FusedAdamW([p], lr=0.1)
+    opt2.step(); opt2.step()                      # cleared: the update runs again
+    assert torch.all(p.detach() < 1.0)
+
+
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize("D", [128, 1920, 3072])
 def test_ln_modulate(dev, D):
@@ -569,6 +626,21 @@ def test_downsample_conv2d_channels_last(dev, N, T, H, W, Cin, Cout):
     y = torch.empty(N, T, H // 2, W // 2, Cout, dtype=BF, device=dev)
     ops.downsample_conv2d(x.to(dev, BF), ops.pack_conv_weight(w).to(dev, BF), b.to(dev, BF), y)
     close(y, ref, 1e-2, 1e-2 * ref.abs().max().item(), "downsample conv2d")
+
+
+@pytest.mark.parametrize("T", [2, 7, 8, 16, 48])
+def test_temporal_pool_all_pairs(dev, T):
+    """DownSample3D's plain avg_pool1d branch (cp_enc_dec.py:658-667; diffusers' rule for an even frame count): pairs (0,1),(2,3).."""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(T)
+    N, H, W, C = 2, 3, 5, 64
+    x = rb(torch.randn(N, T, H, W, C, generator=g))
+    xt = x.permute(0, 2, 3, 4, 1).reshape(N * H * W, C, T)
+    ref = F.avg_pool1d(xt, kernel_size=2, stride=2)
+    ref = ref.reshape(N, H, W, C, T // 2).permute(0, 4, 1, 2, 3)
+    y = torch.empty(N, T // 2, H, W, C, dtype=BF, device=dev)
+    ops.temporal_pool(x.to(dev, BF), y, keep_first=False)
+    close(y, ref, 1e-2, 1e-2, "temporal pool (all pairs)")
 
 
 @pytest.mark.parametrize("T", [1, 2, 5, 8, 49])

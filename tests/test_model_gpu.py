@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("rope", [False, True], ids=["2b_sincos", "5b_rope"])
 def test_tiny_train_step_matches_oracle(dev, rope):
-    from vt355.selfcheck import tiny_train_step_check
+    from selfcheck import tiny_train_step_check
     r = tiny_train_step_check(verbose=True, B=2, rope=rope)
     assert r["cos"] > 0.995
 
@@ -16,7 +16,7 @@ def test_tiny_train_step_matches_oracle(dev, rope):
 def test_forward_no_grad_and_b_zero_init(dev):
     """peft init (B = 0): adapters must not change the forward; dA must be exactly 0 and dB non-zero."""
     import cogvideox_oracle as O
-    from vt355.selfcheck import build_tiny, oracle_params
+    from selfcheck import build_tiny, oracle_params
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.workflow import _LossFn
     cfg, model, peft, st = build_tiny(dev, lora_b_random=False)
@@ -44,7 +44,7 @@ def test_forward_no_grad_and_b_zero_init(dev):
 
 
 def test_grad_accumulation_and_state_dict_filter(dev):
-    from vt355.selfcheck import build_tiny
+    from selfcheck import build_tiny
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.workflow import _LossFn
     cfg, model, peft, st = build_tiny(dev)
@@ -86,7 +86,7 @@ def test_full_finetune_all_parameter_grads_match_oracle(dev, variant):
     from vt355.optim import FusedAdamW
     from vt355.scheduler import CogVideoXDPMScheduler
     from vt355.workflow import _LossFn
-    from vt355.selfcheck import CFG_KEYS
+    from selfcheck import CFG_KEYS
     rope, i2v = variant != "2b", variant == "5b_i2v"
     cfg = O.tiny_config(use_rotary_positional_embeddings=rope, use_learned_positional_embeddings=i2v,
                         in_channels=32 if i2v else 16)
@@ -204,7 +204,7 @@ def test_block_recompute_gives_the_same_gradients(dev, mode):
     from vt355.dit import CogVideoXTransformer3DModel
     from vt355.fullft import enable_full_finetune
     from vt355.scheduler import CogVideoXDPMScheduler
-    from vt355.selfcheck import CFG_KEYS, build_tiny
+    from selfcheck import CFG_KEYS, build_tiny
     from vt355.workflow import _LossFn
     if mode == "lora":
         cfg, model, peft, st = build_tiny(dev)
@@ -270,7 +270,7 @@ def test_lora_loss_curve_tracks_the_oracle_over_optimizer_steps(dev):
     import cogvideox_oracle as O
     from vt355.optim import FusedAdamW
     from vt355.scheduler import CogVideoXDPMScheduler
-    from vt355.selfcheck import build_tiny, oracle_params
+    from selfcheck import build_tiny, oracle_params
     from vt355.workflow import _LossFn
     cfg, model, peft, st = build_tiny(dev)
     Fr = (cfg.sample_frames - 1) // 4 + 1
@@ -334,7 +334,7 @@ def test_full_finetune_loss_curve_tracks_the_oracle(dev):
     from vt355.fullft import enable_full_finetune
     from vt355.optim import FusedAdamW
     from vt355.scheduler import CogVideoXDPMScheduler
-    from vt355.selfcheck import CFG_KEYS
+    from selfcheck import CFG_KEYS
     from vt355.workflow import _LossFn
     cfg = O.tiny_config()
     model = CogVideoXTransformer3DModel(**{k: getattr(cfg, k) for k in CFG_KEYS}).init_weights(11, std=0.05).to(dev)
@@ -412,7 +412,7 @@ def test_training_step_from_raw_batch_through_both_encoders(dev):
     import cogvideox_oracle as O
     from vt355.lora import LoraConfig
     from vt355.prefetch import EncoderPrefetcher
-    from vt355.selfcheck import CFG_KEYS
+    from selfcheck import CFG_KEYS
     from vt355.t5 import FrozenT5Embedder, T5EncoderModel
     from vt355.vae import CogVideoXVaeEncoder
     from vt355.workflow import CogVideoXWorkFlow

@@ -181,3 +181,70 @@ def test_vae_encoder_oracle_matches_reference_twin_golden():
     eps = torch.randn(2, 4, 3, 4, 6)
     lat = V.sample_latent(mom, eps, 0.7)
     assert torch.allclose(lat, (mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * eps) * 0.7)
+
+
+def test_vae_downsample_both_temporal_branches_match_reference_twin():
+    """DownSample3D (cp_enc_dec.py:640-676) run alone by tests/golden/make_golden_vae.py: the rank-0 / fake_cp branch (first frame
+    kept, pairs after it) and the plain avg_pool1d branch, odd and even frame counts.  The encoder follows diffusers' rule: odd ->
+    keep first, even -> plain pairs (even frame counts used to take the odd rule silently)."""
+    import vae_oracle as V
+    g = np.load(os.path.join(G, "vae_downsample3d.npz"))
+    P = {"d.conv.weight": torch.from_numpy(g["ds.conv.weight"]), "d.conv.bias": torch.from_numpy(g["ds.conv.bias"])}
+    for T in (9, 8, 4):
+        x = torch.from_numpy(g[f"x{T}"])
+        kf = V.downsample(x, P, "d.", True, keep_first=True)
+        ap = V.downsample(x, P, "d.", True, keep_first=False)
+        assert torch.equal(kf, torch.from_numpy(g[f"keep_first{T}"])), T
+        assert torch.equal(ap, torch.from_numpy(g[f"all_pairs{T}"])), T
+        auto = V.downsample(x, P, "d.", True)
+        assert torch.equal(auto, kf if T % 2 else ap)
+
+
+def test_dit_block_and_final_layer_composition_match_sat_twin():
+    """The oracle's CogVideoXBlock / final-layer WIRING against the reference's in-tree SAT twin run by
+    tests/golden/make_golden_dit_block.py: AdaLNMixin.layer_forward + attention_fn (dit_video_concat.py:577-701) and
+    FinalLayerMixin.final_forward (:478-498).  The twin's 12-way adaLN chunk (shift,scale,gate)x{msa,mlp} for video then text
+    is mapped onto diffusers' two 6-way CogVideoXLayerNormZero linears (norm1: msa, norm2: mlp; video chunks first)."""
+    g = np.load(os.path.join(G, "sat_dit_block.npz"))
+    T = lambda k: torch.from_numpy(g[k]).double()
+    St, heads = int(g["St"]), int(g["heads"])
+    d = g["hidden"].shape[2]
+    te = g["emb"].shape[1]
+    cfg = O.DiTConfig(num_layers=1, num_attention_heads=heads, attention_head_dim=d // heads, time_embed_dim=te, out_channels=4,
+                      in_channels=4)
+    assert cfg.norm_eps == 1e-5 and cfg.qk_norm_eps == 1e-6
+    W, Bv = T("w.adaLN_modulations.0.1.weight").view(12, d, te), T("w.adaLN_modulations.0.1.bias").view(12, d)
+    pre = "transformer_blocks.0."
+    P = {}
+    for name, idx in (("norm1", [0, 1, 2, 6, 7, 8]), ("norm2", [3, 4, 5, 9, 10, 11])):
+        P[pre + name + ".linear.weight"] = W[idx].reshape(6 * d, te)
+        P[pre + name + ".linear.bias"] = Bv[idx].reshape(6 * d)
+    P[pre + "norm1.norm.weight"], P[pre + "norm1.norm.bias"] = T("w.layer.input_layernorm.weight"), T("w.layer.input_layernorm.bias")
+    P[pre + "norm2.norm.weight"], P[pre + "norm2.norm.bias"] = T("w.layer.post_attention_layernorm.weight"), T("w.layer.post_attention_layernorm.bias")
+    qkv_w, qkv_b = T("w.layer.attention.query_key_value.weight"), T("w.layer.attention.query_key_value.bias")
+    for i, n in enumerate(("to_q", "to_k", "to_v")):
+        P[pre + f"attn1.{n}.weight"], P[pre + f"attn1.{n}.bias"] = qkv_w[i * d:(i + 1) * d], qkv_b[i * d:(i + 1) * d]
+    P[pre + "attn1.to_out.0.weight"], P[pre + "attn1.to_out.0.bias"] = T("w.layer.attention.dense.weight"), T("w.layer.attention.dense.bias")
+    P[pre + "attn1.norm_q.weight"], P[pre + "attn1.norm_q.bias"] = T("w.query_layernorm_list.0.weight"), T("w.query_layernorm_list.0.bias")
+    P[pre + "attn1.norm_k.weight"], P[pre + "attn1.norm_k.bias"] = T("w.key_layernorm_list.0.weight"), T("w.key_layernorm_list.0.bias")
+    P[pre + "ff.net.0.proj.weight"], P[pre + "ff.net.0.proj.bias"] = T("w.layer.mlp.dense_h_to_4h.weight"), T("w.layer.mlp.dense_h_to_4h.bias")
+    P[pre + "ff.net.2.weight"], P[pre + "ff.net.2.bias"] = T("w.layer.mlp.dense_4h_to_h.weight"), T("w.layer.mlp.dense_4h_to_h.bias")
+    hid, emb = T("hidden"), T("emb")
+    # the twin feeds emb through its own nn.SiLU inside adaLN_modulations; so does the oracle's ln_zero
+    ht, hv = O.dit_block(hid[:, :St], hid[:, St:], emb, P, pre, cfg)
+    out = torch.cat([ht, hv], dim=1)
+    ref = T("out")
+    assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item(), (out - ref).abs().max().item()
+    # ---- final layer: the twin has ONE LayerNorm (eps 1e-6) where diffusers has norm_final + norm_out.norm; with an identity
+    # affine on norm_final the second LayerNorm of an already normalised row is the identity to O(eps)
+    import dataclasses
+    cfgf = dataclasses.replace(cfg, norm_eps=1e-6)
+    Pf = {"norm_final.weight": torch.ones(d, dtype=torch.float64), "norm_final.bias": torch.zeros(d, dtype=torch.float64),
+          "norm_out.norm.weight": T("f.norm_final.weight"), "norm_out.norm.bias": T("f.norm_final.bias"),
+          "norm_out.linear.weight": T("f.adaLN_modulation.1.weight"), "norm_out.linear.bias": T("f.adaLN_modulation.1.bias"),
+          "proj_out.weight": T("f.linear.weight"), "proj_out.bias": T("f.linear.bias")}
+    Tn, Hp, Wp = [int(v) for v in g["grid"]]
+    img = O.dit_final(ref[:, St:], emb, Pf, cfgf, Tn, 2 * Hp, 2 * Wp)
+    fref = T("final_out")
+    assert img.shape == fref.shape
+    assert (img - fref).abs().max().item() < 1e-5 * fref.abs().max().item(), (img - fref).abs().max().item()

@@ -42,7 +42,7 @@ PROTOTYPES = {
     "vt_causal_conv3d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     "vt_causal_conv3d_in8_cl": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp],
     "vt_downsample_conv2d_cl": [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
-    "vt_temporal_pool_cl": [_vp, _ll, _vp, _ll, _i, _i, _ll, _i, _vp],
+    "vt_temporal_pool_cl": [_vp, _ll, _vp, _ll, _i, _i, _ll, _i, _i, _vp],
     "vt_rmsnorm_bf16": [_vp, _ll, _vp, _vp, _ll, _ll, _i, _f, _vp],
     "vt_gated_gelu_bf16": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
     "vt_attn_bwd_hd64": [_vp, _vp, _vp, _vp, _vp, _fp, _fp, _fp, _vp, _vp, _i, _i, _i,
@@ -62,7 +62,7 @@ PROTOTYPES = {
     "vt_add_noise": [_fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
     "vt_diffusion_loss": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _f, _vp],
     "vt_diffusion_loss_bwd": [_vp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
-    "vt_adamw": [_fp, _fp, _fp, _fp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp],
+    "vt_adamw": [_fp, _fp, _fp, _fp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp, _vp],
     "vt_lora_down": [_vp, _i, _vp, _i, _i, _vp, _i, _ll, _i, _i, _vp],
     "vt_skinny_tn": [_vp, _i, _vp, _i, _i, _fp, _ll, _ll, _f, _ll, _i, _fp, _vp],
     "vt_skinny_tn_workspace_bytes": [_i],

@@ -12,6 +12,7 @@ from typing import Any
 TARGET_REMAP = {
     "diffusers.CogVideoXTransformer3DModel": "vt355.dit.CogVideoXTransformer3DModel",
     "diffusers.CogVideoXDPMScheduler": "vt355.scheduler.CogVideoXDPMScheduler",
+    "diffusers.AutoencoderKLCogVideoX": "vt355.vae.CogVideoXVaeEncoder",
     "peft.LoraConfig": "vt355.lora.LoraConfig",
     "videotuna.models.cogvideo_hf.cogvideo_pl.CogVideoXWorkFlow": "vt355.workflow.CogVideoXWorkFlow",
     "videotuna.models.cogvideo_hf.cogvideo_i2v.CogVideoXI2V": "vt355.workflow.CogVideoXI2V",
@@ -50,7 +51,23 @@ def instantiate_from_config(config: Any, resolve=False):
     return cls(**params)
 
 
-def load_yaml(path: str) -> dict:
+def load_yaml(path: str, env: dict = None) -> dict:
+    """A reference config file as plain dicts.  ``${NAME}`` placeholders (the shipped YAMLs use them for user paths, e.g.
+    ``csv_path: ${YOUR_DATA_CSV_PATH}``, resolved by OmegaConf in the reference) are filled from ``env`` / os.environ and
+    left as they are when unknown -- they only occur under ``data:``, which this engine does not build."""
+    import re
     import yaml
     with open(path) as f:
-        return yaml.safe_load(f)
+        cfg = yaml.safe_load(f)
+    table = dict(os.environ)
+    table.update(env or {})
+
+    def walk(o):
+        if isinstance(o, dict):
+            return {k: walk(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [walk(v) for v in o]
+        if isinstance(o, str) and "${" in o:
+            return re.sub(r"\$\{([^}]+)\}", lambda m: str(table.get(m.group(1), m.group(0))), o)
+        return o
+    return walk(cfg)

@@ -1,6 +1,6 @@
 // ABI bookkeeping entry points of libvt355.so (see include/vt355.h).
 #include "common.h"
-extern "C" int vt_version(void) { return 1; }
+extern "C" int vt_version(void) { return 2; }
 extern "C" const char* vt_arch(void) { return "gfx950"; }
 extern "C" const char* vt_error_string(int code) {
     switch (code) {

@@ -111,6 +111,7 @@ struct AttnBwdParams {
     float scale, scale_log2;
     int chain_len;        // 1: one workgroup per key block, every one adds its dQ partial atomically; > 1: persistent + chains
     int* chain_ctr;       // [8] = error word                                    (zeroed by the host before the launch)
+                          // [16] = STICKY time-out count: never cleared by the library (the caller zeroes it once and reads it when it likes)
     int* chain_flags;     // [slots][16]: ready[8 waves] | consumed[8 waves], in absolute steps (zeroed before the launch)
     int* chain_xcc;       // [slots] 1 + XCC_ID of the workgroup that runs the slot (0 = not started yet; zeroed before the launch)
     float* chain_tiles;   // [slots][CH_R][4 waves][4][64 lanes][4] fp32
@@ -133,7 +134,9 @@ struct AttnBwdParams {
 #ifndef CH_HYST
 #define CH_HYST 1                // tiles of slack a consumer rebuilds whenever it had to wait for its producer
 #endif
-#define CH_SPIN_LIMIT (1 << 19)   // polls (~1 us each) before a wait gives up
+#ifndef CH_SPIN_LIMIT
+#define CH_SPIN_LIMIT (1 << 19)   // polls (~1 us each) before a wait gives up (-DCH_SPIN_LIMIT=0: the forced-time-out test build, libvt355_test.so)
+#endif
 #define CH_AUX 17                // counters: sc0 | sc1 = system scope -- stores write through, loads bypass the caches
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
@@ -275,7 +278,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             ++spins;
             __builtin_amdgcn_s_sleep(4);
             have = __builtin_amdgcn_readfirstlane(fl_load(off));
-            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; }
+            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; atomicAdd(p.chain_ctr + 16, 1); }
         }
     };
 
@@ -690,7 +693,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             ++spins;
             __builtin_amdgcn_s_sleep(4);
             have = __builtin_amdgcn_readfirstlane(fl_load(off));
-            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; }
+            if (++it > CH_SPIN_LIMIT) { dead = true; p.chain_ctr[8] = 1; atomicAdd(p.chain_ctr + 16, 1); }
         }
     };
 
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(256) void DELTA_KERNEL(const bf16_t* o, const bf16_
     }
 }
 
-// workspace layout: [0,64) error word, diagnostics | [256, +64 slots) counters (ready[8] | consumed[8] per slot) | [.., +4 slots) XCC ids | tiles from the next 4 KiB boundary
+// workspace layout: [0,64) error word, diagnostics of the last launch | [64,256) sticky: int[16] = time-outs since the caller cleared it | [256, +64 slots) counters (ready[8] | consumed[8] per slot) | [.., +4 slots) XCC ids | tiles from the next 4 KiB boundary
 static long long bwd_chain_xcc_off(long long slots) { return 256 + slots * 64; }
 static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 68 + 4095) & ~4095LL; }
 static long long bwd_chain_ws_bytes(long long slots) { return bwd_chain_tiles_off(slots) + slots * (long long)(CH_R * 16384); }
@@ -1404,7 +1407,9 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
     if (chain_ws != nullptr && chain_ws_bytes >= 64 && !(((uintptr_t)chain_ws) & 255)) {
         char* ws = (char*)chain_ws;
         const bool on = L > 1 && chain_ws_bytes >= bwd_chain_ws_bytes(g_bwd_slots);
-        if (hipMemsetAsync(ws, 0, on ? (size_t)bwd_chain_tiles_off(g_bwd_slots) : 64, st) != hipSuccess) return VT_ERR_LAUNCH;
+        // bytes [64, 256) are sticky (ints 16..: time-out count since the caller last cleared it) and survive every launch
+        if (hipMemsetAsync(ws, 0, 64, st) != hipSuccess) return VT_ERR_LAUNCH;
+        if (on && hipMemsetAsync(ws + 256, 0, (size_t)bwd_chain_tiles_off(g_bwd_slots) - 256, st) != hipSuccess) return VT_ERR_LAUNCH;
         if (on) {
             p.chain_len = L;
             p.chain_ctr = (int*)ws;

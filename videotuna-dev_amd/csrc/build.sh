@@ -23,3 +23,13 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIB" "$OBJ"/*.o
 echo "built $OUT/$LIB"
+# libvt355_test.so: the attention backward with CH_SPIN_LIMIT=0 (every dQ hand-off wait that is not satisfied at once times out)
+# under the symbol suffix _tmo -- only tests/ load it (the forced time-out test of the sticky error word / optimizer guard)
+if [ -z "${VT_LIB_NAME:-}" ]; then
+  T="$OBJ/../obj_test"; mkdir -p "$T"
+  if [ ! -f "$T/attn_bwd_tmo.o" ] || [ "$HERE/attn_bwd.hip" -nt "$T/attn_bwd_tmo.o" ] || [ "$HERE/common.h" -nt "$T/attn_bwd_tmo.o" ]; then
+    $HIPCC $FLAGS -DVT_SUFFIX=_tmo -DCH_SPIN_LIMIT=0 -c "$HERE/attn_bwd.hip" -o "$T/attn_bwd_tmo.o"
+  fi
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvt355_test.so" "$T"/*.o
+  echo "built $OUT/libvt355_test.so"
+fi

@@ -199,7 +199,8 @@ extern "C" int vt_diffusion_loss_bwd(const void* vpred, const void* noisy, const
 // ---------------- fused AdamW over one flat fp32 buffer (+ bf16 compute copy) ----------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, long long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                    float gscale) {
+                                                    float gscale, const int* guard) {
+    if (guard != nullptr && *guard != 0) return;      // a kernel of this step flagged its results invalid: refuse the update
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gr = g[i] * gscale;
         float pv = p[i] * (1.0f - lr * wd);
@@ -212,11 +213,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 extern "C" int vt_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, const int* guard,
+                        void* stream) {
     if (n <= 0 || step <= 0) return VT_ERR_BAD_SHAPE;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     long long b = (n + 255) / 256;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, guard);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

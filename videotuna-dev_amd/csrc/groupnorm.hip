@@ -117,9 +117,12 @@ extern "C" int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* ga
 // Temporal compression of the VAE's DownSample3D (compress_time, cp_enc_dec.py:640-657): the first frame is kept, the remaining
 // T - 1 frames are averaged in consecutive pairs (avg_pool1d(kernel 2, stride 2): a trailing odd frame is dropped).
 //   y[n, 0] = x[n, 0];   y[n, 1 + i] = (x[n, 1 + 2i] + x[n, 2 + 2i]) / 2,   To = 1 + (T - 1) / 2      (T == 1: copy)
+// keep_first == 0: plain avg_pool1d(2, 2) over ALL frames, y[n, i] = (x[n, 2i] + x[n, 2i+1]) / 2, To = T / 2 -- the branch the same module
+// takes on context-parallel ranks > 0 / fake_cp=False (cp_enc_dec.py:659-667) and diffusers' CogVideoXDownsample3D takes for an EVEN
+// frame count (the 8-frame chunks after the first 9 of its chunked encode).
 // x: bf16 [N, T, HW, C], y: bf16 [N, To, HW, C] channels-last.
 __global__ __launch_bounds__(256) void temporal_pool_kernel(const bf16_t* x, long long ldx, bf16_t* y, long long ldy, int T, int To,
-                                                            long long HW, int C, long long total) {
+                                                            long long HW, int C, long long total, int keep_first) {
     const int nch = C >> 3;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % nch) * 8;
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(256) void temporal_pool_kernel(const bf16_t* x, lon
         const long long n = nto / To;
         const bf16_t* xs = x + ((n * T) * HW + hw) * ldx + c;
         float a[8];
-        if (to == 0) {
+        if (to == 0 && keep_first) {
             unpack8(*(const u32x4*)xs, a);
         } else {
             float b[8];
-            unpack8(*(const u32x4*)(xs + (long long)(2 * to - 1) * HW * ldx), a);
-            unpack8(*(const u32x4*)(xs + (long long)(2 * to) * HW * ldx), b);
+            unpack8(*(const u32x4*)(xs + (long long)(2 * to - keep_first) * HW * ldx), a);
+            unpack8(*(const u32x4*)(xs + (long long)(2 * to + 1 - keep_first) * HW * ldx), b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = 0.5f * (a[j] + b[j]);
         }
@@ -143,14 +146,17 @@ __global__ __launch_bounds__(256) void temporal_pool_kernel(const bf16_t* x, lon
     }
 }
 
-extern "C" int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, void* stream) {
+extern "C" int vt_temporal_pool_cl(const void* x, long long ldx, void* y, long long ldy, int N, int T, long long HW, int C, int keep_first,
+                                   void* stream) {
+    keep_first = keep_first ? 1 : 0;
+    if (!keep_first && T < 2) return VT_ERR_BAD_SHAPE;
     if (N <= 0 || T <= 0 || HW <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldy % 8) || ldx < C || ldy < C) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return VT_ERR_BAD_ALIGN;
-    const int To = 1 + (T - 1) / 2;
+    const int To = keep_first ? 1 + (T - 1) / 2 : T / 2;
     const long long total = (long long)N * To * HW * (C >> 3);
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(temporal_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
-                       T, To, HW, C, total);
+                       T, To, HW, C, total, keep_first);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

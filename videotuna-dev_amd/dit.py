@@ -242,6 +242,13 @@ class CogVideoXTransformer3DModel(nn.Module):
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
         self._packed = None
+        ft = getattr(self, "fullft", None)
+        if ft is not None:              # the parameters are bf16 views: the fp32 master and the transposed operand copies follow
+            with torch.no_grad():
+                ft.flat.copy_(ft.flat_bf16)
+            ft.mark_changed()
+        if self.lora is not None:
+            self.lora.mark_changed()
         return out
 
     # ----- forward -----

@@ -194,6 +194,14 @@ class _LoraModel(nn.Module):       # peft's ``base_model`` level
     def forward(self, *a, **k):
         return self.model(*a, **k)
 
+    def __getattr__(self, name):        # peft's BaseTuner forwards unknown attributes to the wrapped model as well
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name == "model":
+                raise
+            return getattr(self.model, name)
+
 
 class PeftModel(nn.Module):
     """Minimal stand-in for peft.PeftModel: same key prefix (``base_model.model.``) and attribute pass-through."""

@@ -295,15 +295,21 @@ def downsample_conv2d(x, wk, bias, y):
     return y
 
 
-def temporal_pool(x, y):
-    """x bf16 [N,T,H,W,C] -> y bf16 [N, 1 + (T-1)//2, H, W, C]: first frame kept, the rest averaged in pairs (VAE DownSample3D)"""
+def temporal_pool_frames(T: int, keep_first: bool) -> int:
+    return 1 + (T - 1) // 2 if keep_first else T // 2
+
+
+def temporal_pool(x, y, keep_first: bool = True):
+    """VAE DownSample3D temporal compression, x bf16 [N,T,H,W,C].  keep_first: first frame kept, the rest averaged in pairs ->
+    [N, 1 + (T-1)//2, ...]; not keep_first: all frames averaged in pairs -> [N, T//2, ...] (even frame counts, diffusers' rule)"""
     _req(x, BF16, "x", 5); _req(y, BF16, "y", 5)
     N, T, H, W, C = x.shape
-    if tuple(y.shape) != (N, 1 + (T - 1) // 2, H, W, C):
-        raise ValueError(f"y must be {(N, 1 + (T - 1) // 2, H, W, C)}, got {tuple(y.shape)}")
+    To = temporal_pool_frames(T, keep_first)
+    if tuple(y.shape) != (N, To, H, W, C) or To < 1:
+        raise ValueError(f"y must be {(N, To, H, W, C)}, got {tuple(y.shape)}")
     _cl_check(x, "x"); _cl_check(y, "y")
-    check(load_library().vt_temporal_pool_cl(x.data_ptr(), x.stride(3), y.data_ptr(), y.stride(3), N, T, H * W, C, _stream()),
-          "vt_temporal_pool_cl")
+    check(load_library().vt_temporal_pool_cl(x.data_ptr(), x.stride(3), y.data_ptr(), y.stride(3), N, T, H * W, C, int(keep_first),
+                                             _stream()), "vt_temporal_pool_cl")
     return y
 
 
@@ -324,22 +330,50 @@ def gated_gelu(u, y):
 def attn_bwd_chain_workspace(B: int, H: int, S: int, device) -> Optional[torch.Tensor]:
     """scratch for the dQ hand-off chains of vt_attn_bwd_hd64 (None when the library runs without chains); one buffer
     serves every attention-backward launch of a step"""
+    if _SIDE_STREAMS["n"] > 0:
+        return None          # chained workgroups spin on each other: every one of them must be resident, which nobody can
+                             # promise while kernels of another stream (encoders, collectives) share the CUs
     n = int(load_library().vt_attn_bwd_chain_ws_bytes(B, H, S))
     if n <= 0:
         return None
     key = str(device)
     ws = _CHAIN_WS.get(key)
     if ws is None or ws.numel() < n:
+        old = ws
         ws = _CHAIN_WS[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        ws[:256].zero_()                                    # the sticky words are the caller's to clear, once
+        if old is not None:
+            ws[64:256].copy_(old[64:256])                   # ... and must survive a re-allocation
     return ws
 
 
 _CHAIN_WS = {}      # device -> workspace, reused by every launch on that device (launches of one stream are ordered)
+_SIDE_STREAMS = {"n": 0}
+
+
+def declare_side_stream(active: bool):
+    """Tell the engine that kernels of ANOTHER stream (frozen encoders one step ahead, an overlapped collective) may share the
+    CUs with the backward pass from now on / no longer.  While any is declared the attention backward runs without dQ
+    hand-off chains (plain atomics): the chains' inter-workgroup waits assume that all persistent workgroups are resident."""
+    _SIDE_STREAMS["n"] = max(0, _SIDE_STREAMS["n"] + (1 if active else -1))
+
+
+def chain_guard(device) -> Optional[torch.Tensor]:
+    """int32 [1] view of the STICKY time-out counter of this device's chain workspace (None: no chained launch so far):
+    what FusedAdamW hands to vt_adamw as ``guard``"""
+    ws = _CHAIN_WS.get(str(device))
+    return None if ws is None else ws[64:68].view(torch.int32)
 
 
 def attn_bwd_chain_errors() -> int:
-    """error words of every chain workspace handed out so far (synchronises); non-zero = a dQ hand-off wait timed out"""
-    return sum(attn_bwd_chain_error(ws) for ws in _CHAIN_WS.values())
+    """time-outs of dQ hand-off waits since the workspaces were created (sticky count; synchronises); non-zero = some
+    attention backward produced an invalid dQ"""
+    return sum(int(ws[64:68].view(torch.int32).item()) for ws in _CHAIN_WS.values())
+
+
+def attn_bwd_chain_errors_clear():
+    for ws in _CHAIN_WS.values():
+        ws[64:256].zero_()
 
 
 def gemm_set_tile(mode: int = 0):
@@ -475,11 +509,14 @@ def diffusion_loss_bwd(vpred, noisy, x0, sa, sb, w, grad_out, dvpred):
                                                _stream()), "vt_diffusion_loss_bwd")
 
 
-def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0):
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: float = 1.0, guard: Optional[torch.Tensor] = None):
+    """guard: device int32 [1]; a non-zero value at execution time makes the kernel skip the whole update"""
     for n, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _req(t, torch.float32, n)
+    if guard is not None:
+        _req(guard, torch.int32, "guard")
     check(load_library().vt_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(),
-                                  lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "vt_adamw")
+                                  lr, beta1, beta2, eps, wd, step, grad_scale, _p(guard), _stream()), "vt_adamw")
 
 
 def lora_down(x, a, R: int, t_out, K: int, zero_cols: int = 48):

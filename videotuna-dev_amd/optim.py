@@ -30,6 +30,7 @@ class FusedAdamW:
         self.is_fullft = fullft_state is not None
         lora_state = self.lora_state
         self.step_count = 0
+        self._err_host = self._err_event = None
         if self.is_fullft:
             self.m = torch.zeros_like(fullft_state.flat)
             self.v = torch.zeros_like(fullft_state.flat)
@@ -50,23 +51,49 @@ class FusedAdamW:
                 if p.grad is not None:
                     p.grad.zero_()
 
+    def check_errors(self, wait: bool = True):
+        """Raise if a kernel of an EARLIER step flagged its gradients invalid (a timed-out dQ hand-off of the attention
+        backward: that step's update was refused on the device by vt_adamw's guard).  The flag travels to a pinned host
+        word by an async copy queued behind each step; by the next step it has long arrived, so this does not stall."""
+        if self._err_event is None:
+            return
+        if not wait and not self._err_event.query():
+            return
+        self._err_event.synchronize()
+        self._err_event = None
+        n = int(self._err_host.item())
+        if n:
+            from ._lib import VtError
+            raise VtError(f"{n} dQ hand-off wait(s) of the attention backward timed out (persistent workgroups were not co-resident): "
+                          "the gradients of that step were invalid and its optimizer update was skipped on the device. "
+                          "Declare concurrent streams with vt355.ops.declare_side_stream(True) or set VT_BWD_CHAIN=1.")
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None
+        self.check_errors()
         self.step_count += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
+        dev = self.params[0].device
+        guard = ops.chain_guard(dev) if dev.type == "cuda" else None
         if self.lora_state is not None:
             st = self.lora_state
             ops.adamw(st.flat, st.grad, self.m, self.v, st.flat_bf16, g["lr"], b1, b2, g["eps"], g["weight_decay"],
-                      self.step_count, grad_scale)
+                      self.step_count, grad_scale, guard)
             st.version += 1            # packed K-extension columns are refreshed at the next forward
         else:
             for p, m, v in zip(self.params, self.m, self.v):
                 if p.grad is None:
                     continue
                 ops.adamw(p.data, p.grad, m, v, None, g["lr"], b1, b2, g["eps"], g["weight_decay"], self.step_count,
-                          grad_scale)
+                          grad_scale, guard)
+        if guard is not None:
+            if self._err_host is None:
+                self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._err_host.copy_(guard, non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record(torch.cuda.current_stream(dev))
         return loss
 
     def state_dict(self):

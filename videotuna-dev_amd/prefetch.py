@@ -58,12 +58,19 @@ class EncoderPrefetcher:
     def __iter__(self) -> Iterator[Dict[str, Any]]:
         it = iter(self.batches)
         queue = []
-        for raw in it:
-            queue.append(self._launch(raw))
-            if len(queue) > self.depth:
+        if self.on_gpu:                 # encoder kernels will share the CUs with the DiT's backward from here on: the
+            from . import ops           # attention backward must not rely on all its persistent workgroups being resident
+            ops.declare_side_stream(True)
+        try:
+            for raw in it:
+                queue.append(self._launch(raw))
+                if len(queue) > self.depth:
+                    yield self._hand_over(*queue.pop(0))
+            while queue:
                 yield self._hand_over(*queue.pop(0))
-        while queue:
-            yield self._hand_over(*queue.pop(0))
+        finally:
+            if self.on_gpu:
+                ops.declare_side_stream(False)
 
     def _hand_over(self, out, ev):
         if ev is not None:

@@ -114,6 +114,7 @@ class CogVideoXVaeEncoder(nn.Module):
         self._packed = None
 
     # ------------------------------------------------------------------ weights
+    _CTOR_KEYS = ("in_channels", "ch", "ch_mult", "num_res_blocks", "z_channels", "double_z", "temporal_compress_times", "scaling_factor")
     _PREFIXES = ("first_stage_model.encoder.", "encoder.")      # full SAT / autoencoder checkpoints carry the encoder under these
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -125,15 +126,31 @@ class CogVideoXVaeEncoder(nn.Module):
             if any(k.startswith(pre) for k in sd):
                 sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
                 break
+        if any(k.startswith(("down_blocks.", "mid_block.")) or ".resnets." in k for k in sd):
+            raise KeyError("this looks like a diffusers AutoencoderKLCogVideoX checkpoint (keys like encoder.down_blocks.N.resnets.M...): "
+                           "that key layout is not supported (diffusers is absent offline, the map cannot be verified); convert to the "
+                           "SAT / in-tree twin names (down.N.block.M..., cogvideo_sat/vae_modules/cp_enc_dec.py) -- see INTEGRATION.md")
         return super().load_state_dict({k: v.to(BF16) for k, v in sd.items()}, strict=strict, **kw)
 
     @classmethod
-    def from_pretrained(cls, path: str, **config):
-        """``path``: a .safetensors file (or a directory holding ``model.safetensors`` / ``diffusion_pytorch_model.safetensors``) with
-        the in-tree twin's parameter names; ``config`` overrides the CogVideoX defaults.  Nothing is fetched."""
+    def from_pretrained(cls, path: str = None, pretrained_model_name_or_path: str = None, subfolder: str = None, **config):
+        """``path`` (or the reference YAML's ``pretrained_model_name_or_path`` + ``subfolder``, configs/004_cogvideox/*.yaml:6-10): a
+        .safetensors file (or a directory holding ``model.safetensors`` / ``diffusion_pytorch_model.safetensors``) with the in-tree
+        twin's parameter names; ``config`` overrides the CogVideoX defaults.  Nothing is fetched."""
         import os
         from safetensors.torch import load_file
+        if path is None:
+            path = os.path.join(pretrained_model_name_or_path, subfolder or "")
+        config = {k: v for k, v in config.items() if k in cls._CTOR_KEYS}
         if os.path.isdir(path):
+            cj = os.path.join(path, "config.json")
+            if os.path.exists(cj):              # scaling_factor (2B: 1.15258426, 5B: 0.7) and any constructor key the file states
+                import json
+                with open(cj) as f:
+                    cfg_file = json.load(f)
+                for k in cls._CTOR_KEYS:
+                    if k in cfg_file and k not in config:
+                        config[k] = cfg_file[k]
             for fn in ("model.safetensors", "diffusion_pytorch_model.safetensors"):
                 if os.path.exists(os.path.join(path, fn)):
                     path = os.path.join(path, fn)
@@ -224,8 +241,12 @@ class CogVideoXVaeEncoder(nn.Module):
             if i != nlev - 1:
                 Bq, Tq, Hq, Wq, Cq = h.shape
                 if i < self.temporal_levels and Tq > 1:
-                    hp = torch.empty(Bq, 1 + (Tq - 1) // 2, Hq, Wq, Cq, dtype=BF16, device=dev)
-                    ops.temporal_pool(h, hp)
+                    # odd frame count: first frame kept, pairs after it (the in-tree twin's rank-0 branch, cp_enc_dec.py:645-657);
+                    # even: plain pairs over all frames (its other branch, :658-667) -- the rule of diffusers' CogVideoXDownsample3D,
+                    # whose chunked encode feeds 9 frames first and 8-frame chunks after that
+                    keep_first = (Tq % 2 == 1)
+                    hp = torch.empty(Bq, ops.temporal_pool_frames(Tq, keep_first), Hq, Wq, Cq, dtype=BF16, device=dev)
+                    ops.temporal_pool(h, hp, keep_first)
                     h = hp
                 hd = torch.empty(Bq, h.shape[1], Hq // 2, Wq // 2, Cq, dtype=BF16, device=dev)
                 ops.downsample_conv2d(h, pk[f"down.{i}.downsample.conv"], lvl.downsample.conv.bias, hd)

@@ -46,7 +46,19 @@ class CogVideoXWorkFlow(nn.Module):
         super().__init__()
         self.logdir = logdir
         self.learning_rate = learning_rate
-        self.first_stage, self.cond_stage = first_stage, cond_stage       # optional frozen encoders (out of scope)
+        # frozen encoders: explicit callables win; else the config nodes are honoured when their checkpoints exist LOCALLY
+        # (cogvideo_pl.py:104-121 builds them unconditionally; offline a model name such as "DeepFloyd/t5-v1_1-xxl" cannot
+        # be fetched -> the stage stays None and batches must come pre-encoded, see get_batch_input)
+        self.first_stage, self.cond_stage = first_stage, cond_stage
+        if first_stage is None and first_stage_config is not None:
+            vae = self._optional_stage(first_stage_config)
+            if vae is not None:
+                self.vae = vae
+                self.first_stage = vae.latents
+        if cond_stage is None and cond_stage_config is not None:
+            self.cond_stage_model = self._optional_stage(cond_stage_config)
+            if self.cond_stage_model is not None:
+                self.cond_stage = self.cond_stage_model
         self.vae_scale_factor_spatial, self.vae_scale_factor_temporal = 8, 4
         self.model = instantiate_from_config(denoiser_config)
         params = denoiser_config.get("params", {}) if isinstance(denoiser_config, dict) else {}
@@ -60,6 +72,16 @@ class CogVideoXWorkFlow(nn.Module):
         self.model.enable_gradient_checkpointing()
         self.global_step = 0
         self._rope_cache: Dict[tuple, Any] = {}
+
+    @staticmethod
+    def _optional_stage(node):
+        """instantiate a frozen-encoder node, or None when it points at weights that are not on this machine"""
+        params = (node.get("params") or {}) if isinstance(node, dict) else {}
+        path = params.get("pretrained_model_name_or_path") or params.get("version")
+        import os
+        if path is None or not os.path.isdir(os.path.join(path, params.get("subfolder") or "")):
+            return None
+        return instantiate_from_config(node)
 
     @property
     def dtype(self):
@@ -179,7 +201,8 @@ class CogVideoXI2V(CogVideoXWorkFlow):
                                    "{'latents','image_latents','prompt_embeds'}")
             with torch.no_grad():
                 vids = torch.cat([self.first_stage(v) for v in batch["video"]], dim=0)
-                imgs = torch.cat([self.first_stage(im.unsqueeze(1)) for im in batch["image"]], dim=0)
+                # reference schema: image [3,1,H,W] (cogvideo_i2v.py:65-68); a plain [3,H,W] frame gets its time axis here
+                imgs = torch.cat([self.first_stage(im.unsqueeze(1) if im.dim() == 3 else im) for im in batch["image"]], dim=0)
                 emb = self.cond_stage([c for c in batch["caption"]])
         vids = vids.permute(0, 2, 1, 3, 4).contiguous()           # [B,C,T,H,W] -> [B,T,C,H,W]
         imgs = imgs.permute(0, 2, 1, 3, 4).contiguous()

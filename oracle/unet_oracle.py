@@ -1,0 +1,398 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the VideoCrafter2 denoiser: the lvdm 3D UNet
+(BASELINE configs[3]) and the LVDM training loss (a15).  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s cpu_baseline may import this file.
+
+What it follows (all under /root/reference/videotuna/models/lvdm/):
+  * UNetModel.forward ............ modules/networks/openaimodel3d.py:650-694 (time / fps embedding 651-660, context and emb
+                                    repeat_interleave over frames 664-665, input blocks + init_attn 671-681, middle 685, output
+                                    blocks with skip concat 686-688, GroupNorm -> SiLU -> conv 690)
+  * TimestepEmbedSequential ...... :33-53 (ResBlock gets (emb, batch_size), SpatialTransformer the context, TemporalTransformer
+                                    the (b f) c h w -> b c f h w view)
+  * ResBlock._forward ............ :229-255 (GroupNorm32 fp32 -> SiLU -> conv3x3; + Linear(SiLU(emb)); GroupNorm -> SiLU ->
+                                    dropout -> conv3x3; skip (identity | 1x1 conv); TemporalConvBlock)
+  * TemporalConvBlock ............ :258-310 (4 x [GroupNorm(32) -> SiLU -> (dropout) -> Conv3d (3,1,1)], + identity)
+  * Downsample / Upsample ........ :56-120 (conv3x3 stride 2 padding 1; nearest x2 then conv3x3)
+  * SpatialTransformer ........... modules/attention.py:313-392 (GroupNorm(32, eps 1e-6) -> Linear in -> blocks -> Linear out -> + x)
+  * TemporalTransformer .......... :395-519 (same over the frame axis, per pixel; only_self_att: both attentions are self-attention)
+  * BasicTransformerBlock ........ :299-310 (x += attn1(LN(x)); x += attn2(LN(x), context); x += FF(LN(x)))
+  * CrossAttention.forward ....... :101-181 (q/k/v Linear without bias, context[:, :77], softmax(q k^T * d^-0.5) v, Linear out + bias)
+  * GEGLU / FeedForward .......... :522-548 (proj -> chunk (x, gate) -> x * gelu(gate) [erf GELU] -> Linear)
+  * GroupNormSpecific ............ modules/utils.py:192-203 (fp32 statistics, eps 1e-5)
+  * timestep_embedding ........... videotuna/utils/diffusion_utils.py:9-33 (cos first)
+  * loss ......................... ddpm3d.py:787-847 / flow/videocrafter.py:418-474 (eps-prediction MSE; logvar weighting is the
+                                    identity while logvar == 0, learn_logvar False)
+Not restated (off in configs/001_videocrafter2/vc2_t2v_320x512.yaml): use_scale_shift_norm, resblock_updown, relative position
+tables, causal temporal mask, image cross-attention, tempspatial_aware, non-linear proj_in (use_linear: true).
+
+PARITY STATUS: pinned.  tests/golden/unet_*.npz hold outputs and gradients of the reference's own modules (UNetModel and each
+block alone) imported in the build container by tests/golden/make_golden_unet.py on weights from ``init_params`` below;
+tests/test_oracle_golden.py checks this restatement against them.  Parameter names are the reference's state_dict keys.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    attention_resolutions: Tuple[int, ...] = (4, 2, 1)
+    num_res_blocks: int = 2
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_head_channels: int = 64
+    transformer_depth: int = 1
+    context_dim: int = 1024
+    temporal_conv: bool = True
+    temporal_attention: bool = True
+    temporal_length: int = 16
+    addition_attention: bool = True
+    fps_cond: bool = True
+    text_context_len: int = 77
+
+
+def tiny_config(**kw) -> UNetConfig:
+    base = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1, 2), context_dim=64,
+                temporal_length=4)
+    base.update(kw)
+    return UNetConfig(**base)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# structure: the module tree of UNetModel.__init__ (openaimodel3d.py:341-648) as a list of layer descriptors per block
+# ---------------------------------------------------------------------------------------------------------------
+def structure(cfg: UNetConfig):
+    """-> dict(input=[[layer...]...], init_attn=layer|None, middle=[layer...], output=[[layer...]...]); a layer is
+    (kind, prefix, info) with kind in conv_in | res | st | tt | down | up"""
+    mc = cfg.model_channels
+    inp = [[("conv_in", "input_blocks.0.0", dict(cin=cfg.in_channels, cout=mc))]]
+    chans = [mc]
+    ch, ds = mc, 1
+    hd = cfg.num_head_channels
+    idx = 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            layers = [("res", f"input_blocks.{idx}.0", dict(cin=ch, cout=mult * mc, tconv=cfg.temporal_conv))]
+            ch = mult * mc
+            if ds in cfg.attention_resolutions:
+                layers.append(("st", f"input_blocks.{idx}.1", dict(c=ch, heads=ch // hd, inner=ch)))
+                if cfg.temporal_attention:
+                    layers.append(("tt", f"input_blocks.{idx}.2", dict(c=ch, heads=ch // hd, inner=ch)))
+            inp.append(layers); chans.append(ch); idx += 1
+        if level != len(cfg.channel_mult) - 1:
+            inp.append([("down", f"input_blocks.{idx}.0", dict(c=ch))]); chans.append(ch); idx += 1
+            ds *= 2
+    init_attn = ("tt", "init_attn.0", dict(c=mc, heads=8, inner=8 * hd)) if cfg.addition_attention else None
+    mid = [("res", "middle_block.0", dict(cin=ch, cout=ch, tconv=cfg.temporal_conv)),
+           ("st", "middle_block.1", dict(c=ch, heads=ch // hd, inner=ch))]
+    if cfg.temporal_attention:
+        mid.append(("tt", "middle_block.2", dict(c=ch, heads=ch // hd, inner=ch)))
+    mid.append(("res", f"middle_block.{len(mid)}", dict(cin=ch, cout=ch, tconv=cfg.temporal_conv)))
+    out = []
+    idx = 0
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            layers = [("res", f"output_blocks.{idx}.0", dict(cin=ch + ich, cout=mult * mc, tconv=cfg.temporal_conv))]
+            ch = mult * mc
+            if ds in cfg.attention_resolutions:
+                layers.append(("st", f"output_blocks.{idx}.{len(layers)}", dict(c=ch, heads=ch // hd, inner=ch)))
+                if cfg.temporal_attention:
+                    layers.append(("tt", f"output_blocks.{idx}.{len(layers)}", dict(c=ch, heads=ch // hd, inner=ch)))
+            if level and i == cfg.num_res_blocks:
+                layers.append(("up", f"output_blocks.{idx}.{len(layers)}", dict(c=ch)))
+                ds //= 2
+            out.append(layers); idx += 1
+    return dict(input=inp, init_attn=init_attn, middle=mid, output=out, out_ch=ch)
+
+
+def _transformer_shapes(sh, pre, c, inner, ctx_dim: Optional[int], conv1d: bool = False):
+    """SpatialTransformer / TemporalTransformer parameters (use_linear: true, depth 1); ctx_dim None: attn2 is self-attention.
+    conv1d: init_attn is built WITHOUT use_linear (openaimodel3d.py:418-432), its proj_in / proj_out are Conv1d(kernel 1):
+    the same arithmetic as a Linear, weights carry a trailing unit axis"""
+    k1 = (1,) if conv1d else ()
+    sh[pre + ".norm.weight"] = (c,); sh[pre + ".norm.bias"] = (c,)
+    sh[pre + ".proj_in.weight"] = (inner, c) + k1; sh[pre + ".proj_in.bias"] = (inner,)
+    b = pre + ".transformer_blocks.0."
+    def attn(a, kd):
+        sh[b + a + ".to_q.weight"] = (inner, inner)
+        sh[b + a + ".to_k.weight"] = (inner, kd)
+        sh[b + a + ".to_v.weight"] = (inner, kd)
+        sh[b + a + ".to_out.0.weight"] = (inner, inner); sh[b + a + ".to_out.0.bias"] = (inner,)
+    attn("attn1", inner)                       # registration order of BasicTransformerBlock: attn1, ff, attn2, norm1..3
+    sh[b + "ff.net.0.proj.weight"] = (8 * inner, inner); sh[b + "ff.net.0.proj.bias"] = (8 * inner,)
+    sh[b + "ff.net.2.weight"] = (inner, 4 * inner); sh[b + "ff.net.2.bias"] = (inner,)
+    attn("attn2", inner if ctx_dim is None else ctx_dim)
+    for n in ("norm1", "norm2", "norm3"):
+        sh[b + n + ".weight"] = (inner,); sh[b + n + ".bias"] = (inner,)
+    sh[pre + ".proj_out.weight"] = (c, inner) + k1; sh[pre + ".proj_out.bias"] = (c,)
+
+
+def param_shapes(cfg: UNetConfig) -> Dict[str, tuple]:
+    """state_dict keys of the reference UNetModel, in its registration order"""
+    mc, te = cfg.model_channels, 4 * cfg.model_channels
+    sh: Dict[str, tuple] = {}
+    embeds = ["time_embed"] + (["fps_embedding"] if cfg.fps_cond else [])
+    for n in embeds:
+        sh[n + ".0.weight"] = (te, mc); sh[n + ".0.bias"] = (te,)
+        sh[n + ".2.weight"] = (te, te); sh[n + ".2.bias"] = (te,)
+    st = structure(cfg)
+
+    def add_layer(kind, pre, info):
+        if kind == "conv_in":
+            sh[pre + ".weight"] = (info["cout"], info["cin"], 3, 3); sh[pre + ".bias"] = (info["cout"],)
+        elif kind == "res":
+            ci, co = info["cin"], info["cout"]
+            sh[pre + ".in_layers.0.weight"] = (ci,); sh[pre + ".in_layers.0.bias"] = (ci,)
+            sh[pre + ".in_layers.2.weight"] = (co, ci, 3, 3); sh[pre + ".in_layers.2.bias"] = (co,)
+            sh[pre + ".emb_layers.1.weight"] = (co, te); sh[pre + ".emb_layers.1.bias"] = (co,)
+            sh[pre + ".out_layers.0.weight"] = (co,); sh[pre + ".out_layers.0.bias"] = (co,)
+            sh[pre + ".out_layers.3.weight"] = (co, co, 3, 3); sh[pre + ".out_layers.3.bias"] = (co,)
+            if ci != co:
+                sh[pre + ".skip_connection.weight"] = (co, ci, 1, 1); sh[pre + ".skip_connection.bias"] = (co,)
+            if info["tconv"]:
+                for j, ci_ in ((1, 0), (2, 0), (3, 0), (4, 0)):
+                    last = 2 if j == 1 else 3
+                    sh[pre + f".temopral_conv.conv{j}.0.weight"] = (co,); sh[pre + f".temopral_conv.conv{j}.0.bias"] = (co,)
+                    sh[pre + f".temopral_conv.conv{j}.{last}.weight"] = (co, co, 3, 1, 1)
+                    sh[pre + f".temopral_conv.conv{j}.{last}.bias"] = (co,)
+        elif kind == "st":
+            _transformer_shapes(sh, pre, info["c"], info["inner"], cfg.context_dim)
+        elif kind == "tt":
+            _transformer_shapes(sh, pre, info["c"], info["inner"], None, conv1d=pre.startswith("init_attn"))
+        elif kind == "down":
+            sh[pre + ".op.weight"] = (info["c"], info["c"], 3, 3); sh[pre + ".op.bias"] = (info["c"],)
+        elif kind == "up":
+            sh[pre + ".conv.weight"] = (info["c"], info["c"], 3, 3); sh[pre + ".conv.bias"] = (info["c"],)
+
+    for blk in st["input"]:
+        for l in blk:
+            add_layer(*l)
+    if st["init_attn"] is not None:          # registered after the whole input_blocks list (openaimodel3d.py:410-432)
+        add_layer(*st["init_attn"])
+    for l in st["middle"]:
+        add_layer(*l)
+    for blk in st["output"]:
+        for l in blk:
+            add_layer(*l)
+    sh["out.0.weight"] = (st["out_ch"],); sh["out.0.bias"] = (st["out_ch"],)
+    sh["out.2.weight"] = (cfg.out_channels, mc, 3, 3); sh["out.2.bias"] = (cfg.out_channels,)
+    return sh
+
+
+def init_params(cfg: UNetConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded init for fixtures and synthetic benchmarks (no checkpoints offline): matrices ~ N(0, 1/fan_in) scaled so that
+    activations stay O(1) through the residual stack, norm gamma ~ 1 + N(0, 0.1), biases / beta ~ N(0, 0.1).  Nothing is
+    exactly zero -- the reference zero-initialises proj_out / out_layers[3] / conv4 / out[2] (openaimodel3d.py:192,300,647;
+    attention.py:369-373), which would hide every gradient behind them."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, s in param_shapes(cfg).items():
+        if len(s) == 1:
+            w = torch.randn(s, generator=g) * 0.1
+            if k.endswith("weight"):          # 1-d weights are norm scales
+                w = w + 1.0
+        else:
+            fan_in = 1
+            for d in s[1:]:
+                fan_in *= d
+            w = torch.randn(s, generator=g) * (0.7 / math.sqrt(fan_in))
+        out[k] = w.to(dtype)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# functional forward
+# ---------------------------------------------------------------------------------------------------------------
+def timestep_embedding(t, dim, max_period=10000):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def group_norm32(x, w, b, eps=1e-5):
+    """GroupNormSpecific: statistics in fp32 whatever the activation dtype (utils.py:192-194)"""
+    return F.group_norm(x.float(), 32, w.float(), b.float(), eps).to(x.dtype)
+
+
+def cross_attention(x, P, pre, heads, context=None, text_len=77):
+    """CrossAttention.forward, einsum path (attention.py:101-181); context None: self-attention"""
+    q = F.linear(x, P[pre + ".to_q.weight"])
+    ctx = x if context is None else context[:, :text_len]
+    k = F.linear(ctx, P[pre + ".to_k.weight"])
+    v = F.linear(ctx, P[pre + ".to_v.weight"])
+    B, N, C = q.shape
+    d = C // heads
+    sp = lambda t: t.reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3)
+    q, k, v = sp(q), sp(k), sp(v)
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * (d ** -0.5)
+    o = torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v)
+    o = o.permute(0, 2, 1, 3).reshape(B, N, C)
+    return F.linear(o, P[pre + ".to_out.0.weight"], P[pre + ".to_out.0.bias"])
+
+
+def feed_forward(x, P, pre):
+    h = F.linear(x, P[pre + ".net.0.proj.weight"], P[pre + ".net.0.proj.bias"])
+    a, gate = h.chunk(2, dim=-1)
+    return F.linear(a * F.gelu(gate), P[pre + ".net.2.weight"], P[pre + ".net.2.bias"])
+
+
+def basic_block(x, P, pre, heads, context, text_len=77):
+    C = x.shape[-1]
+    ln = lambda t, n: F.layer_norm(t, (C,), P[pre + n + ".weight"], P[pre + n + ".bias"], 1e-5)
+    x = cross_attention(ln(x, "norm1"), P, pre + "attn1", heads) + x
+    x = cross_attention(ln(x, "norm2"), P, pre + "attn2", heads, context, text_len) + x
+    x = feed_forward(ln(x, "norm3"), P, pre + "ff") + x
+    return x
+
+
+def spatial_transformer(x, context, P, pre, heads, text_len=77):
+    """x [(b t), c, h, w], context [(b t), L, ctx]"""
+    b, c, h, w = x.shape
+    x_in = x
+    x = F.group_norm(x, 32, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-6)
+    x = x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+    x = F.linear(x, P[pre + ".proj_in.weight"], P[pre + ".proj_in.bias"])
+    x = basic_block(x, P, pre + ".transformer_blocks.0.", heads, context, text_len)
+    x = F.linear(x, P[pre + ".proj_out.weight"], P[pre + ".proj_out.bias"])
+    x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
+    return x + x_in
+
+
+def temporal_transformer(x, P, pre, heads):
+    """x [b, c, t, h, w]; only_self_att: no context reaches the blocks (attention.py:487-491)"""
+    b, c, t, h, w = x.shape
+    x_in = x
+    x = F.group_norm(x, 32, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-6)
+    x = x.permute(0, 3, 4, 2, 1).reshape(b * h * w, t, c)
+    w2 = lambda n: P[n].reshape(P[n].shape[0], P[n].shape[1])      # Conv1d(kernel 1) of init_attn == Linear
+    x = F.linear(x, w2(pre + ".proj_in.weight"), P[pre + ".proj_in.bias"])
+    x = basic_block(x, P, pre + ".transformer_blocks.0.", heads, None)
+    x = F.linear(x, w2(pre + ".proj_out.weight"), P[pre + ".proj_out.bias"])
+    x = x.reshape(b, h, w, t, c).permute(0, 4, 3, 1, 2)
+    return x + x_in
+
+
+def temporal_conv_block(x, P, pre):
+    """x [b, c, t, h, w]; dropout (0.1 in the reference's train mode) is the identity here: fixtures are taken in eval mode"""
+    idn = x
+    for j in (1, 2, 3, 4):
+        last = 2 if j == 1 else 3
+        x = F.group_norm(x, 32, P[pre + f".conv{j}.0.weight"], P[pre + f".conv{j}.0.bias"], 1e-5)
+        x = F.conv3d(F.silu(x), P[pre + f".conv{j}.{last}.weight"], P[pre + f".conv{j}.{last}.bias"], padding=(1, 0, 0))
+    return x + idn
+
+
+def res_block(x, emb, P, pre, batch_size, tconv=True):
+    """x [(b t), c, h, w], emb [(b t), 4*mc]"""
+    h = group_norm32(x, P[pre + ".in_layers.0.weight"], P[pre + ".in_layers.0.bias"])
+    h = F.conv2d(F.silu(h), P[pre + ".in_layers.2.weight"], P[pre + ".in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), P[pre + ".emb_layers.1.weight"], P[pre + ".emb_layers.1.bias"])
+    h = h + e[:, :, None, None]
+    h = group_norm32(h, P[pre + ".out_layers.0.weight"], P[pre + ".out_layers.0.bias"])
+    h = F.conv2d(F.silu(h), P[pre + ".out_layers.3.weight"], P[pre + ".out_layers.3.bias"], padding=1)
+    if (pre + ".skip_connection.weight") in P:
+        x = F.conv2d(x, P[pre + ".skip_connection.weight"], P[pre + ".skip_connection.bias"])
+    h = x + h
+    if tconv and batch_size:
+        bt, c, hh, ww = h.shape
+        h5 = h.reshape(batch_size, bt // batch_size, c, hh, ww).permute(0, 2, 1, 3, 4)
+        h5 = temporal_conv_block(h5, P, pre + ".temopral_conv")
+        h = h5.permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww)
+    return h
+
+
+def _run_block(layers, h, emb, context, b, P, cfg):
+    for kind, pre, info in layers:
+        if kind == "conv_in":
+            h = F.conv2d(h, P[pre + ".weight"], P[pre + ".bias"], padding=1)
+        elif kind == "res":
+            h = res_block(h, emb, P, pre, b, info["tconv"])
+        elif kind == "st":
+            h = spatial_transformer(h, context, P, pre, info["heads"], cfg.text_context_len)
+        elif kind == "tt":
+            bt, c, hh, ww = h.shape
+            h5 = h.reshape(b, bt // b, c, hh, ww).permute(0, 2, 1, 3, 4)
+            h5 = temporal_transformer(h5, P, pre, info["heads"])
+            h = h5.permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww)
+        elif kind == "down":
+            h = F.conv2d(h, P[pre + ".op.weight"], P[pre + ".op.bias"], stride=2, padding=1)
+        elif kind == "up":
+            h = F.interpolate(h, scale_factor=2, mode="nearest")
+            h = F.conv2d(h, P[pre + ".conv.weight"], P[pre + ".conv.bias"], padding=1)
+    return h
+
+
+def unet_forward(P: Dict[str, torch.Tensor], cfg: UNetConfig, x, timesteps, context, fps=16, taps: Optional[dict] = None):
+    """x [B, C, T, H, W], timesteps int64 [B], context [B, L, ctx_dim], fps int | int64 [B] -> [B, C_out, T, H, W]"""
+    dt = x.dtype
+    mc = cfg.model_channels
+    lin = lambda v, n: F.linear(v, P[n + ".weight"], P[n + ".bias"])
+    emb = lin(F.silu(lin(timestep_embedding(timesteps, mc).to(dt), "time_embed.0")), "time_embed.2")
+    if cfg.fps_cond:
+        if isinstance(fps, int):
+            fps = torch.full_like(timesteps, fps)
+        emb = emb + lin(F.silu(lin(timestep_embedding(fps, mc).to(dt), "fps_embedding.0")), "fps_embedding.2")
+    b, _, t, hh, ww = x.shape
+    context = context.repeat_interleave(t, dim=0)
+    emb = emb.repeat_interleave(t, dim=0)
+    h = x.permute(0, 2, 1, 3, 4).reshape(b * t, -1, hh, ww)
+    st = structure(cfg)
+    hs = []
+    for i, blk in enumerate(st["input"]):
+        h = _run_block(blk, h, emb, context, b, P, cfg)
+        if i == 0 and st["init_attn"] is not None:
+            h = _run_block([st["init_attn"]], h, emb, context, b, P, cfg)
+        hs.append(h)
+        if taps is not None:
+            taps[f"input{i}"] = h
+    h = _run_block(st["middle"], h, emb, context, b, P, cfg)
+    if taps is not None:
+        taps["middle"] = h
+    for i, blk in enumerate(st["output"]):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _run_block(blk, h, emb, context, b, P, cfg)
+        if taps is not None:
+            taps[f"output{i}"] = h
+    h = group_norm32(h, P["out.0.weight"], P["out.0.bias"])
+    y = F.conv2d(F.silu(h), P["out.2.weight"], P["out.2.bias"], padding=1)
+    return y.reshape(b, t, -1, hh, ww).permute(0, 2, 1, 3, 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LVDM training loss (eps-prediction): q_sample -> UNet -> MSE
+# ---------------------------------------------------------------------------------------------------------------
+def lddpm_alphas_cumprod(timesteps=1000, linear_start=0.00085, linear_end=0.012):
+    """make_beta_schedule("linear") (diffusion_utils.py:36-45): betas = linspace(sqrt(s), sqrt(e), n)^2 in float64"""
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def q_sample(x0, t, noise, abar):
+    sa = abar[t].sqrt().view(-1, 1, 1, 1, 1).to(x0.dtype)
+    sb = (1 - abar[t]).sqrt().view(-1, 1, 1, 1, 1).to(x0.dtype)
+    return sa * x0 + sb * noise
+
+
+def lvdm_loss(eps_pred, noise):
+    """ddpm3d.py:819-847 with parameterization eps, loss_type l2, logvar == 0, l_simple_weight 1, original_elbo_weight 0:
+    loss_simple = mean over (c,t,h,w) per sample; loss = mean_b(loss_simple / exp(0) + 0)"""
+    return ((eps_pred - noise) ** 2).mean(dim=(1, 2, 3, 4)).mean()
+
+
+def scale_arr(num_timesteps=1000, scale_a=1.0, scale_b=0.7, mid_step=400, fix_scale_bug=False):
+    """dynamic rescaling table of the latent before q_sample (ddpm3d.py:500-514, applied at :740-741 `x = x * scale_arr[t]`;
+    vc2 yaml: use_scale true, scale_b 0.7).  With the reference's default (fix_scale_bug False) the table is 1400 long."""
+    import numpy as np
+    step = num_timesteps - mid_step if fix_scale_bug else num_timesteps
+    return torch.tensor(np.concatenate((np.linspace(scale_a, scale_b, mid_step), np.full(step, scale_b))), dtype=torch.float32)

@@ -248,3 +248,86 @@ def test_dit_block_and_final_layer_composition_match_sat_twin():
     fref = T("final_out")
     assert img.shape == fref.shape
     assert (img - fref).abs().max().item() < 1e-5 * fref.abs().max().item(), (img - fref).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ VideoCrafter2 UNet
+def _unet_params():
+    import unet_oracle as U
+    cfg = U.tiny_config()
+    return U, cfg, {k: v.double() for k, v in U.init_params(cfg, seed=11).items()}
+
+
+def _sub(P, pre):
+    return {k: v for k, v in P.items() if k.startswith(pre)}
+
+
+def test_unet_oracle_matches_reference_unet_output_and_gradients():
+    """oracle/unet_oracle.py vs the reference's own UNetModel (openaimodel3d.py:313-694) run by tests/golden/make_golden_unet.py:
+    output, eps-MSE loss, checksums of ALL 626 parameter gradients and 15 gradients in full."""
+    U, cfg, P = _unet_params()
+    g = np.load(os.path.join(G, "unet_tiny.npz"))
+    for v in P.values():
+        v.requires_grad_(True)
+    T = lambda k: torch.from_numpy(g[k])
+    out = U.unet_forward(P, cfg, T("x").double(), T("t"), T("context").double(), fps=T("fps"))
+    ref = T("out").double()
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    loss = U.lvdm_loss(out, T("noise").double())
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    names = list(P)
+    gs = np.array([P[n].grad.sum().item() for n in names]); ga = np.array([P[n].grad.abs().sum().item() for n in names])
+    assert np.allclose(ga, g["grad_abs_sum"], rtol=2e-4, atol=1e-7), np.abs(ga - g["grad_abs_sum"]).max()
+    assert np.allclose(gs, g["grad_sum"], rtol=0, atol=2e-4 * np.abs(g["grad_abs_sum"]).max())
+    full = [k[5:] for k in g.files if k.startswith("grad.")]
+    assert len(full) == 15
+    for n in full:
+        r = torch.from_numpy(g["grad." + n]).double()
+        assert (P[n].grad - r).abs().max().item() < 2e-4 * r.abs().max().item() + 1e-9, n
+
+
+def test_unet_oracle_blocks_match_reference_blocks():
+    """each block alone (ResBlock with temporal conv + 1x1 skip, TemporalConvBlock, SpatialTransformer, TemporalTransformer,
+    CrossAttention with a context longer than 77, Downsample, Upsample): output, input gradients, every parameter gradient"""
+    U, cfg, P = _unet_params()
+    g = np.load(os.path.join(G, "unet_blocks.npz"))
+    T = lambda k: torch.from_numpy(g[k]).double()
+
+    def check(tag, pre, fn, nin):
+        for v in P.values():
+            v.grad = None
+            v.requires_grad_(True)
+        ins = [T(f"{tag}.in{i}").requires_grad_(True) for i in range(nin)]
+        y = fn(*ins)
+        ref = T(tag + ".y")
+        assert (y - ref).abs().max().item() < 2e-5 * ref.abs().max().item(), tag
+        (y * T(tag + ".gy")).sum().backward()
+        for i in range(nin):
+            r = T(f"{tag}.gin{i}")
+            assert (ins[i].grad - r).abs().max().item() < 1e-4 * r.abs().max().item(), (tag, i)
+        keys = [k for k in g.files if k.startswith(tag + ".g.")]
+        assert keys
+        for k in keys:
+            r = T(k)
+            got = P[pre + k[len(tag) + 3:]].grad
+            assert (got - r).abs().max().item() < 1e-4 * r.abs().max().item() + 1e-10, k
+
+    check("res", "input_blocks.3.0.", lambda a, e: U.res_block(a, e, P, "input_blocks.3.0", 2, True), 2)
+    check("tconv", "input_blocks.1.0.temopral_conv.", lambda a: U.temporal_conv_block(a, P, "input_blocks.1.0.temopral_conv"), 1)
+    check("st", "input_blocks.1.1.", lambda a, c: U.spatial_transformer(a, c, P, "input_blocks.1.1", 1), 2)
+    check("tt", "input_blocks.1.2.", lambda a: U.temporal_transformer(a, P, "input_blocks.1.2", 1), 1)
+    check("xattn", "input_blocks.1.1.transformer_blocks.0.attn2.",
+          lambda a, c: U.cross_attention(a, P, "input_blocks.1.1.transformer_blocks.0.attn2", 1, c), 2)
+    check("down", "input_blocks.2.0.", lambda a: U._run_block([("down", "input_blocks.2.0", {})], a, None, None, 1, P, cfg), 1)
+    check("up", "output_blocks.1.3.", lambda a: U._run_block([("up", "output_blocks.1.3", {})], a, None, None, 1, P, cfg), 1)
+
+
+def test_lvdm_schedule_and_q_sample_match_reference():
+    import unet_oracle as U
+    g = np.load(os.path.join(G, "unet_loss.npz"))
+    ab = U.lddpm_alphas_cumprod()
+    assert np.allclose(ab.numpy(), g["alphas_cumprod"], rtol=1e-6)
+    xn = U.q_sample(torch.from_numpy(g["x0"]), torch.from_numpy(g["t"]), torch.from_numpy(g["noise"]), ab)
+    assert np.allclose(xn.numpy(), g["q_sample"], rtol=1e-5, atol=1e-6)
+    sa = U.scale_arr()
+    assert sa.shape[0] == 1400 and abs(sa[0].item() - 1.0) < 1e-7 and abs(sa[399].item() - 0.7) < 1e-7 and abs(sa[999].item() - 0.7) < 1e-7

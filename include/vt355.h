@@ -252,6 +252,68 @@ int vt_lora_up_add(void* dX, int ldx, const void* dT, int ldt, const void* A, in
 int vt_lora_pack_b(const float* Bcat, void* Wext, int ldw, int n_adapters, int d_out, int r, float scale, void* stream);
 int vt_lora_pack_bt(const float* Bcat, void* WText, int ldwt, int n_adapters, int d_out, int r, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * VideoCrafter2 UNet path (BASELINE configs[3]): lvdm UNetModel.forward and its backward
+ * (videotuna/models/lvdm/modules/networks/openaimodel3d.py:650-694) on ONE channels-last layout [B, T, H, W, C].
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+
+/* Zero-padded convolution as an implicit GEMM:  y[n,t,ho,wo,co] = bias[co] + sbias[n,co] + res[...] + sum_{dt,dh,dw,ci}
+ * x[n, t+dt-pt, ho*stride+dh-ph, wo*stride+dw-pw, ci] * wk[co, (dt,dh,dw), ci].  x bf16 [N,T,H,W,Cin] (position stride ldx), wk bf16
+ * [Cout, KT*KH*KW*Cin] = the torch weight permuted to [Cout, KT, KH, KW, Cin]; y bf16 [N,T,Ho,Wo,Cout]; bias bf16 [Cout] | NULL;
+ * sbias fp32 [N, sbias_ld] | NULL (per-sample bias: ResBlock's `h + emb_out[..., None, None]`, openaimodel3d.py:245); res bf16 like
+ * y | NULL.  2*pt == KT-1 (no temporal stride), Cin % 64 == 0, Cout % 4 == 0, x spans < 2 GiB.
+ * Replaces: Conv2d 3x3 of ResBlock / Upsample / out (openaimodel3d.py:166-170, 193, 110-112, 647), Downsample.op (stride 2, :71-79),
+ * Conv3d (3,1,1) of TemporalConvBlock (:278-296); with the flipped, transposed weight it is also their input gradient. */
+int vt_conv_cl(const void* x, long long ldx, const void* wk, const void* bias, const float* sbias, int sbias_ld,
+               const void* res, long long ldr, void* y, long long ldy,
+               int N, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int pt, int ph, int pw, int stride, void* stream);
+/* Weight gradient of the same convolution: dw[co, tap, ci] (+)= sum_m dy[m, co] * x[shift(m, tap), ci]; dw fp32 [Cout, taps*Cin],
+ * overwritten or (accumulate != 0) added to.  One tap, no padding: the weight gradient of an nn.Linear of any (multiple-of-8) size.
+ * Replaces: autograd's conv / linear weight gradients under loss.backward(). */
+int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long long ldx, float* dw,
+                  int N, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int pt, int ph, int pw, int stride,
+                  int accumulate, void* stream);
+/* Backward of vt_groupnorm_silu_cl.  ws_fwd: the workspace the forward call left (mean | rstd | a | b per (n, c)); ws_bwd: scratch of
+ * vt_groupnorm_ws_bytes(N, C) bytes; dgamma / dbeta fp32 [C] ACCUMULATED (NULL: skipped); dx overwritten, or added to when
+ * accumulate != 0.  Replaces: autograd of GroupNormSpecific / nn.GroupNorm (+ SiLU) (lvdm/modules/utils.py:192-203). */
+int vt_groupnorm_silu_bwd_cl(const void* dy, long long lddy, const void* x, long long ldx, const void* gamma,
+                             const float* ws_fwd, float* ws_bwd, long long ws_bytes, void* dx, long long lddx,
+                             float* dgamma, float* dbeta, int N, long long P, int C, int G, int silu, int accumulate, void* stream);
+/* GEGLU (lvdm/modules/attention.py:522-529): h [M, 2F] = (a | gate) from the projection; y = a * gelu(gate) (erf GELU) */
+int vt_geglu_fwd(const void* h, long long ldh, void* y, long long ldy, long long M, int F, void* stream);
+int vt_geglu_bwd(const void* dy, long long lddy, const void* h, long long ldh, void* dh, long long lddh, long long M, int F, void* stream);
+/* out[m,:] = a[m,:] + b[m,:] (bf16 rows; gradient accumulation where a tensor feeds two consumers) */
+int vt_add_rows_bf16(const void* a, long long lda, const void* b, long long ldb, void* out, long long ldo, long long M, int C, void* stream);
+/* Row maps on [.., C] bf16 rows, out (+)= src[map]: mode 0: [nb, d1, d2, C] -> [nb, d2, d1, C] (the `b c t h w <-> (b h w) t c`
+ * rearranges of TemporalTransformer.forward, attention.py:476-481, 509-516); 1: nearest x2 upsample [nb, d1, d2] -> [nb, 2 d1, 2 d2]
+ * (Upsample.forward, openaimodel3d.py:112-120); 2: zero insertion, same shapes (input gradient of the stride-2 Downsample.op);
+ * 3: 2x2 block sum [nb, 2 d1, 2 d2] -> [nb, d1, d2] (backward of 1). */
+int vt_row_map_bf16(const void* src, long long lds, void* out, long long ldo, int mode, long long nb, int d1, int d2, int C,
+                    int accumulate, void* stream);
+/* q_sample (videotuna/schedulers/ddpm.py:216-222) with the dynamic rescaling of lvdm/ddpm3d.py:740-741:
+ * x_t = sqrt_ab[b] * scale[b] * x0 + sqrt_1mab[b] * noise (fp32 in, bf16 out; scale NULL = 1) */
+int vt_q_sample(const float* x0, const float* noise, const float* sqrt_ab, const float* sqrt_1mab, const float* scale, void* xt,
+                long long per_sample, int B, void* stream);
+/* eps-prediction loss of LVDMFlow.p_losses (lvdm/ddpm3d.py:787-847, logvar == 0): loss[0] = mean (pred - target)^2;
+ * dpred (bf16 | NULL) = d loss / d pred * grad_scale */
+int vt_mse_loss(const void* pred, const float* target, float* loss, void* dpred, long long total, float grad_scale, void* stream);
+
+/* Attention against <= 128 resident keys, head_dim 64 (csrc/attn_small.hip).  Element (item b, row s, head h, d) at
+ * base + b*bs + s*rs + h*64 + d.  mask_block == 0: NB items of Sq queries x Sk keys -- the text cross-attention attn2 of
+ * SpatialTransformer's BasicTransformerBlock (lvdm/modules/attention.py:101-181; item = sample, the T*H*W positions of a sample share
+ * its 77 text keys).  mask_block = T (32 % T == 0): q, k, v, o are ONE row space of Sq rows = consecutive sequences of T rows, a row
+ * attends to its own sequence -- both attentions of TemporalTransformer (attention.py:395-519) on pixel-major rows; NB = 1, Sk = Sq,
+ * batch strides ignored.  lse2: fp32 [NB, H, Sq].  Backward: dq bf16 like q; mask_block > 0: dk, dv bf16 in the k / v row space;
+ * mask_block == 0: dk32, dv32 fp32 [NB, Sk, dk_rs] accumulators ZEROED BY THE CALLER. */
+int vt_attn_small_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int NB, int H, int Sq, int Sk,
+                      long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs, long long v_bs,
+                      long long o_rs, long long o_bs, float softmax_scale, int mask_block, void* stream);
+int vt_attn_small_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2,
+                      void* dq, void* dk, void* dv, float* dk32, float* dv32, int NB, int H, int Sq, int Sk,
+                      long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs, long long v_bs,
+                      long long o_rs, long long o_bs, long long do_rs, long long do_bs, long long dq_rs, long long dq_bs,
+                      long long dk_rs, long long dv_rs, float softmax_scale, int mask_block, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,250 @@
+"""GPU parity of the VideoCrafter2 UNet kernels (csrc/convnd.hip, unet_ops.hip, attn_small.hip) through the C-ABI against
+fp32 / fp64 PyTorch-CPU restatements of the same ops on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(t):
+    return t.to(BF).float()
+
+
+def close(got, ref, rtol, atol, what):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    assert bool((err <= lim).all()), f"{what}: max err {err.max().item():.3e} (ref max {ref.abs().max().item():.3e}) at {int((err - lim).argmax())}"
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+CONV_CASES = [
+    # N, T, H, W, Cin, Cout, kernel, padding, stride
+    (2, 2, 8, 8, 64, 128, (1, 3, 3), (0, 1, 1), 1),       # ResBlock conv 3x3
+    (1, 3, 5, 7, 128, 64, (1, 3, 3), (0, 1, 1), 1),       # ragged positions
+    (2, 4, 6, 5, 64, 64, (3, 1, 1), (1, 0, 0), 1),        # TemporalConvBlock (3,1,1)
+    (2, 2, 8, 12, 64, 64, (1, 3, 3), (0, 1, 1), 2),       # Downsample stride 2, padding 1
+    (1, 2, 6, 6, 64, 4, (1, 3, 3), (0, 1, 1), 1),         # out conv: 4 output channels
+    (1, 1, 4, 4, 192, 320, (1, 1, 1), (0, 0, 0), 1),      # 1x1 skip connection, Cout not a tile multiple
+]
+
+
+def _conv_ref(x, w, b, kernel, padding, stride):
+    """x [N,T,H,W,Cin] fp32 -> [N,T,Ho,Wo,Cout] with torch's conv3d (Conv2d == one temporal tap)"""
+    xi = x.permute(0, 4, 1, 2, 3)
+    w5 = w if w.dim() == 5 else w[:, :, None]
+    y = F.conv3d(xi, w5, b, stride=(1, stride, stride), padding=padding)
+    return y.permute(0, 2, 3, 4, 1)
+
+
+@pytest.mark.parametrize("N,T,H,W,Cin,Cout,kernel,padding,stride", CONV_CASES)
+def test_conv_cl_forward_input_grad_weight_grad(dev, N, T, H, W, Cin, Cout, kernel, padding, stride):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(H * W + Cout + Cin)
+    KT, KH, KW = kernel
+    x = rb(torch.randn(N, T, H, W, Cin, generator=g))
+    wshape = (Cout, Cin, KH, KW) if KT == 1 else (Cout, Cin, KT, KH, KW)
+    w = rb(torch.randn(wshape, generator=g) / math.sqrt(Cin * KT * KH * KW))
+    b = rb(torch.randn(Cout, generator=g) * 0.1)
+    sb = torch.randn(N, Cout, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    ref = _conv_ref(xr, wr, b, kernel, padding, stride) + sb[:, None, None, None, :]
+    res = rb(torch.randn(ref.shape, generator=g))
+    dy = rb(torch.randn(ref.shape, generator=g))
+    (ref * dy).sum().backward()
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    # ---- forward (+ bias, per-sample bias, residual), input slice of a wider buffer ----
+    xb = torch.zeros(N, T, H, W, Cin + 64, dtype=BF, device=dev)
+    xb[..., :Cin] = x.to(dev, BF)
+    y = torch.empty(N, T, Ho, Wo, Cout, dtype=BF, device=dev)
+    ops.conv_cl(xb[..., :Cin], ops.pack_conv_weight_nd(w).to(dev, BF), y, kernel, padding, stride, bias=b.to(dev, BF), sbias=sb.to(dev),
+                residual=res.to(dev, BF))
+    close(y, ref.detach() + res, 2e-2, 2e-2 * ref.abs().max().item(), "conv forward")
+    # ---- weight gradient ----
+    dw = torch.zeros(Cout, KT * KH * KW * Cin, device=dev)
+    dyd = torch.zeros(N, T, Ho, Wo, (Cout + 7) // 8 * 8, dtype=BF, device=dev)[..., :Cout]       # rows are 16-byte multiples
+    dyd.copy_(dy.to(dev, BF))
+    ops.conv_dw_cl(dyd, xb[..., :Cin], dw, kernel, padding, stride, accumulate=False)
+    dwr = ops.pack_conv_weight_nd(wr.grad)
+    close(dw, dwr, 2e-2, 2e-2 * dwr.abs().max().item(), "conv weight gradient")
+    ops.conv_dw_cl(dyd, xb[..., :Cin], dw, kernel, padding, stride, accumulate=True)
+    close(dw, 2 * dwr, 2e-2, 4e-2 * dwr.abs().max().item(), "conv weight gradient (accumulate)")
+    # ---- input gradient: the same kernel with the flipped, transposed weight (stride 1) / on the zero-inserted dy (stride 2) ----
+    if Cout % 64:
+        return
+    wdx = ops.pack_conv_weight_dx(w if w.dim() == 5 else w[:, :, None]).to(dev, BF)
+    dx = torch.empty(N, T, H, W, Cin, dtype=BF, device=dev)
+    if stride == 1:
+        ops.conv_cl(dy.to(dev, BF), wdx, dx, kernel, padding, 1)
+    else:
+        z = torch.empty(N, T, H, W, Cout, dtype=BF, device=dev)
+        ops.row_map(dy.to(dev, BF).view(-1, Cout), z.view(-1, Cout), 2, N * T, Ho, Wo)
+        ops.conv_cl(z, wdx, dx, kernel, padding, 1)
+    close(dx, xr.grad, 2e-2, 2e-2 * xr.grad.abs().max().item(), "conv input gradient")
+
+
+@pytest.mark.parametrize("M,P,Q", [(1000, 320, 320), (77, 64, 1024), (4096, 2560, 320), (300, 8, 72)])
+def test_linear_dw_any_size(dev, M, P, Q):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + P)
+    dy = rb(torch.randn(M, P, generator=g)); x = rb(torch.randn(M, Q, generator=g))
+    ref = dy.double().t() @ x.double()
+    dw = torch.full((P, Q), 7.0, device=dev)
+    ops.linear_dw(dy.to(dev, BF), x.to(dev, BF), dw, accumulate=False)
+    close(dw, ref, 1e-2, 1e-2 * ref.abs().max().item(), "linear dW")
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm backward
+@pytest.mark.parametrize("N,P,C,silu,eps", [(2, 50, 64, True, 1e-5), (3, 33, 320, True, 1e-5), (2, 64, 128, False, 1e-6), (1, 20, 2560, True, 1e-5)])
+def test_groupnorm_forward_backward(dev, N, P, C, silu, eps):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(C + P)
+    x = rb(torch.randn(N, P, C, generator=g) * 1.5 + 0.3)
+    ga = rb(1 + 0.2 * torch.randn(C, generator=g)); be = rb(0.2 * torch.randn(C, generator=g))
+    dy = rb(torch.randn(N, P, C, generator=g))
+    xr = x.clone().double().requires_grad_(True); gr = ga.double().requires_grad_(True); br = be.double().requires_grad_(True)
+    y = F.group_norm(xr.permute(0, 2, 1), 32, gr, br, eps).permute(0, 2, 1)
+    if silu:
+        y = F.silu(y)
+    (y * dy.double()).sum().backward()
+    xd = x.to(dev, BF); yd = torch.empty_like(xd)
+    ws = ops.groupnorm_fwd(xd, ga.to(dev, BF), be.to(dev, BF), yd, 32, eps, silu)
+    close(yd, y, 2e-2, 2e-2, "groupnorm forward")
+    dx = torch.empty_like(xd)
+    dga = torch.zeros(C, device=dev); dbe = torch.zeros(C, device=dev)
+    ops.groupnorm_bwd(dy.to(dev, BF), xd, ga.to(dev, BF), ws, dx, dga, dbe, 32, silu)
+    close(dx, xr.grad, 3e-2, 2e-2 * xr.grad.abs().max().item(), "groupnorm dx")
+    close(dga, gr.grad, 2e-2, 2e-2 * gr.grad.abs().max().item(), "groupnorm dgamma")
+    close(dbe, br.grad, 2e-2, 2e-2 * br.grad.abs().max().item(), "groupnorm dbeta")
+    base = rb(torch.randn(N, P, C, generator=g))
+    dx2 = base.to(dev, BF).clone()
+    ops.groupnorm_bwd(dy.to(dev, BF), xd, ga.to(dev, BF), ws, dx2, None, None, 32, silu, accumulate=True)
+    close(dx2, xr.grad + base, 3e-2, 3e-2 * xr.grad.abs().max().item(), "groupnorm dx (accumulate)")
+
+
+# ------------------------------------------------------------------------------------------------ GEGLU, row maps, loss
+def test_geglu_forward_backward(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(3)
+    M, Fd = 77, 320
+    h = rb(torch.randn(M, 2 * Fd, generator=g) * 2); dy = rb(torch.randn(M, Fd, generator=g))
+    hr = h.clone().double().requires_grad_(True)
+    a, gate = hr.chunk(2, dim=-1)
+    y = a * F.gelu(gate)
+    (y * dy.double()).sum().backward()
+    yd = torch.empty(M, Fd, dtype=BF, device=dev)
+    ops.geglu_fwd(h.to(dev, BF), yd)
+    close(yd, y, 1e-2, 1e-2, "geglu")
+    dh = torch.empty(M, 2 * Fd, dtype=BF, device=dev)
+    ops.geglu_bwd(dy.to(dev, BF), h.to(dev, BF), dh)
+    close(dh, hr.grad, 1e-2, 2e-2, "geglu backward")
+
+
+def test_row_maps_add_and_loss(dev):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, HW, C = 2, 4, 6, 64
+    x = rb(torch.randn(B, T, HW, C, generator=g))
+    xd = x.to(dev, BF).view(-1, C)
+    out = torch.empty(B * HW * T, C, dtype=BF, device=dev)
+    ops.row_map(xd, out, 0, B, T, HW)
+    assert torch.equal(out.float().cpu().view(B, HW, T, C), x.permute(0, 2, 1, 3))
+    back = torch.empty_like(xd)
+    ops.row_map(out, back, 0, B, HW, T)
+    assert torch.equal(back, xd)
+    N, H, W = 3, 2, 3
+    s = rb(torch.randn(N, H, W, C, generator=g))
+    up = torch.empty(N * 4 * H * W, C, dtype=BF, device=dev)
+    ops.row_map(s.to(dev, BF).view(-1, C), up, 1, N, H, W)
+    ref = s.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    assert torch.equal(up.float().cpu().view(N, 2 * H, 2 * W, C), ref)
+    ops.row_map(s.to(dev, BF).view(-1, C), up, 2, N, H, W)
+    z = torch.zeros(N, 2 * H, 2 * W, C); z[:, ::2, ::2] = s
+    assert torch.equal(up.float().cpu().view(N, 2 * H, 2 * W, C), z)
+    big = rb(torch.randn(N, 2 * H, 2 * W, C, generator=g))
+    dn = torch.empty(N * H * W, C, dtype=BF, device=dev)
+    ops.row_map(big.to(dev, BF).view(-1, C), dn, 3, N, H, W)
+    close(dn.view(N, H, W, C), big.view(N, H, 2, W, 2, C).sum(dim=(2, 4)), 1e-2, 1e-2, "2x2 block sum")
+    ops.row_map(big.to(dev, BF).view(-1, C), dn, 3, N, H, W, accumulate=True)
+    close(dn.view(N, H, W, C), 2 * big.view(N, H, 2, W, 2, C).sum(dim=(2, 4)), 1e-2, 2e-2, "2x2 block sum (accumulate)")
+    a = rb(torch.randn(10, C, generator=g)); b = rb(torch.randn(10, C, generator=g))
+    o = torch.empty(10, C, dtype=BF, device=dev)
+    ops.add_rows(a.to(dev, BF), b.to(dev, BF), o)
+    close(o, a + b, 1e-2, 1e-2, "add rows")
+    # q_sample + eps-MSE loss
+    x0 = torch.randn(2, 4, 4, 8, 8, generator=g); nz = torch.randn(x0.shape, generator=g)
+    sa = torch.tensor([0.9, 0.3]); sb = torch.tensor([0.4, 0.95]); sc = torch.tensor([1.0, 0.7])
+    xt = torch.empty(x0.shape, dtype=BF, device=dev)
+    ops.q_sample(x0.to(dev), nz.to(dev), sa.to(dev), sb.to(dev), sc.to(dev), xt)
+    close(xt, (sa * sc).view(2, 1, 1, 1, 1) * x0 + sb.view(2, 1, 1, 1, 1) * nz, 1e-2, 1e-2, "q_sample")
+    pred = rb(torch.randn(x0.shape, generator=g))
+    loss = torch.empty(1, device=dev); dp = torch.empty(x0.shape, dtype=BF, device=dev)
+    ops.mse_loss(pred.to(dev, BF), nz.to(dev), loss, dp, grad_scale=0.5)
+    ref = ((pred - nz) ** 2).mean(dim=(1, 2, 3, 4)).mean()
+    assert abs(loss.item() - ref.item()) < 1e-4 * ref.item()
+    close(dp, 0.5 * 2 * (pred - nz) / pred.numel(), 1e-2, 1e-6, "mse gradient")
+
+
+# ------------------------------------------------------------------------------------------------ short-key attention
+def _attn_ref(q, k, v, scale, mask_block=0):
+    """q [NB,H,Sq,64], k/v [NB,H,Sk,64] float64"""
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    if mask_block:
+        i = torch.arange(q.shape[2])[:, None] // mask_block
+        j = torch.arange(k.shape[2])[None, :] // mask_block
+        s = s.masked_fill(i != j, float("-inf"))
+    return torch.einsum("bhij,bhjd->bhid", s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("NB,H,Sq,Sk", [(2, 2, 300, 77), (1, 5, 1500, 77), (3, 1, 40, 20), (1, 2, 130, 128)])
+def test_attn_small_cross(dev, NB, H, Sq, Sk):
+    """text cross-attention (CrossAttention.forward, lvdm/modules/attention.py:101-181): every query of a sample against its <= 128 keys"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(Sq + Sk)
+    D = H * 64
+    q = rb(torch.randn(NB, Sq, D, generator=g)); kv = rb(torch.randn(NB, Sk, 2 * D, generator=g))
+    do = rb(torch.randn(NB, Sq, D, generator=g))
+    sp = lambda t: t.double().view(t.shape[0], t.shape[1], H, 64).permute(0, 2, 1, 3)
+    qr, kr, vr = sp(q).requires_grad_(True), sp(kv[..., :D]).requires_grad_(True), sp(kv[..., D:]).requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, 0.125)
+    (ref * sp(do)).sum().backward()
+    mg = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], D)
+    qd, kvd = q.to(dev, BF), kv.to(dev, BF)
+    o = torch.empty(NB, Sq, D, dtype=BF, device=dev); lse = torch.empty(NB, H, Sq, device=dev)
+    ops.attn_small_fwd(qd, kvd[..., :D], kvd[..., D:], o, lse, H, 0.125)
+    close(o, mg(ref), 2e-2, 1e-2, "cross-attention output")
+    dq = torch.empty(NB, Sq, D, dtype=BF, device=dev)
+    dk = torch.empty(NB, Sk, D, device=dev); dv = torch.empty(NB, Sk, D, device=dev)
+    ops.attn_small_bwd(qd, kvd[..., :D], kvd[..., D:], o, do.to(dev, BF), lse, dq, dk, dv, H, 0.125)
+    for got, r, nm in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+        close(got, mg(r), 3e-2, 2e-2 * r.abs().max().item(), "cross-attention " + nm)
+
+
+@pytest.mark.parametrize("R,T,H", [(256, 16, 2), (80, 16, 1), (40960, 16, 5), (72, 4, 8), (33 * 8, 8, 1)])
+def test_attn_small_packed_sequences(dev, R, T, H):
+    """temporal self-attention (TemporalTransformer, attention.py:395-519): R / T consecutive sequences of T rows, fused qkv"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(R + T)
+    D = H * 64
+    big = R > 5000
+    qkv = rb(torch.randn(R, 3 * D, generator=g))
+    do = rb(torch.randn(R, D, generator=g))
+    d = qkv.to(dev, BF).view(1, R, 3 * D)
+    o = torch.empty(1, R, D, dtype=BF, device=dev); lse = torch.empty(1, H, R, device=dev)
+    ops.attn_small_fwd(d[..., :D], d[..., D:2 * D], d[..., 2 * D:], o, lse, H, 0.125, mask_block=T)
+    dqkv = torch.empty(1, R, 3 * D, dtype=BF, device=dev)
+    ops.attn_small_bwd(d[..., :D], d[..., D:2 * D], d[..., 2 * D:], o, do.to(dev, BF).view(1, R, D), lse,
+                       dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], H, 0.125, mask_block=T)
+    rows = slice(R - 2048, R) if big else slice(0, R)          # the full first-level size: check the last 128 sequences
+    n = (rows.stop - rows.start) // T
+    x = qkv[rows].double().view(n, T, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)   # [3, n, H, T, 64]
+    ref = _attn_ref(x[0], x[1], x[2], 0.125)
+    (ref * do[rows].double().view(n, T, H, 64).permute(0, 2, 1, 3)).sum().backward()
+    close(o[0, rows], ref.permute(0, 2, 1, 3).reshape(n * T, D), 2e-2, 1e-2, "temporal attention output")
+    gref = x.grad.permute(1, 3, 0, 2, 4).reshape(n * T, 3 * D)
+    close(dqkv[0, rows], gref, 3e-2, 2e-2 * gref.abs().max().item(), "temporal attention dqkv")

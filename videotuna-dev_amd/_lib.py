@@ -69,6 +69,18 @@ PROTOTYPES = {
     "vt_lora_up_add": [_vp, _i, _vp, _i, _vp, _i, _i, _ll, _i, _vp],
     "vt_lora_pack_b": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
     "vt_lora_pack_bt": [_fp, _vp, _i, _i, _i, _i, _f, _vp],
+    # ---- VideoCrafter2 UNet path ----
+    "vt_conv_cl": [_vp, _ll, _vp, _vp, _fp, _i, _vp, _ll, _vp, _ll] + [_i] * 13 + [_vp],
+    "vt_conv_dw_cl": [_vp, _ll, _vp, _ll, _fp] + [_i] * 13 + [_i, _vp],
+    "vt_groupnorm_silu_bwd_cl": [_vp, _ll, _vp, _ll, _vp, _fp, _fp, _ll, _vp, _ll, _fp, _fp, _i, _ll, _i, _i, _i, _i, _vp],
+    "vt_geglu_fwd": [_vp, _ll, _vp, _ll, _ll, _i, _vp],
+    "vt_geglu_bwd": [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _vp],
+    "vt_add_rows_bf16": [_vp, _ll, _vp, _ll, _vp, _ll, _ll, _i, _vp],
+    "vt_row_map_bf16": [_vp, _ll, _vp, _ll, _i, _ll, _i, _i, _i, _i, _vp],
+    "vt_q_sample": [_fp, _fp, _fp, _fp, _fp, _vp, _ll, _i, _vp],
+    "vt_mse_loss": [_vp, _fp, _fp, _vp, _ll, _f, _vp],
+    "vt_attn_small_fwd": [_vp, _vp, _vp, _vp, _fp, _i, _i, _i, _i] + [_ll] * 8 + [_f, _i, _vp],
+    "vt_attn_small_bwd": [_vp, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp, _fp, _fp, _i, _i, _i, _i] + [_ll] * 14 + [_f, _i, _vp],
 }
 _RESTYPE = {"vt_arch": C.c_char_p, "vt_error_string": C.c_char_p, "vt_skinny_tn_workspace_bytes": C.c_longlong,
              "vt_attn_bwd_chain_ws_bytes": C.c_longlong, "vt_groupnorm_ws_bytes": C.c_longlong}

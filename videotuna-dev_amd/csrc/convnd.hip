@@ -1,0 +1,374 @@
+// Zero-padded N-d convolution over channels-last activations as an implicit GEMM on the matrix cores (gfx950), forward / input
+// gradient and weight gradient: the convolutions of the VideoCrafter2 UNet (BASELINE configs[3]).
+//   ResBlock.in_layers[2] / out_layers[3] / Upsample.conv / UNetModel.out[2] ... Conv2d 3x3, padding 1
+//       (videotuna/models/lvdm/modules/networks/openaimodel3d.py:166-170, 193, 110-112, 647)
+//   Downsample.op ............................................................ Conv2d 3x3, stride 2, padding 1 (:71-79)
+//   TemporalConvBlock.conv1..4 ............................................... Conv3d (3,1,1), padding (1,0,0)  (:278-296)
+// The reference runs them on NCHW / NCTHW tensors through cuDNN with `(b t) c h w <-> b c t h w` copies in between
+// (openaimodel3d.py:249-253); here one channels-last buffer [N, T, H, W, C] serves all of them: a Conv2d is the kernel with
+// one temporal tap, the temporal convolution the kernel with one spatial tap.
+//
+//   y[n,t,ho,wo,co] = bias[co] + sbias[n,co] + res[n,t,ho,wo,co]
+//                     + sum_{dt,dh,dw,ci} x[n, t+dt-pt, ho*s+dh-ph, wo*s+dw-pw, ci] * wk[co, (dt,dh,dw), ci]      (zeros outside)
+// GEMM view: M = output positions, N = Cout, K = taps * Cin; 128x128x64 tile, LDS-DMA staging (buffer_load ... lds), XOR swizzle
+// and MFMA loop of gemm_bf16.hip / conv3d.hip; the row a lane fetches for output position m and a tap is the shifted input
+// position or an always-out-of-range offset (zeros).  No im2col buffer.  sbias (fp32 [N, Cout]) is the ResBlock's
+// `h + emb_out[..., None, None]` (:245) folded into the convolution that produces h.
+// The INPUT gradient of a stride-1 convolution is the same kernel on dY with the flipped, transposed weight (host packs it);
+// the WEIGHT gradient is conv_dw_kernel below.
+#include "common.h"
+#include <stdlib.h>
+
+struct ConvNdParams {
+    const bf16_t* x; const bf16_t* w; bf16_t* y;
+    const bf16_t* bias;      // [Cout] or null
+    const float* sbias;      // fp32 [N, sbias_ld] or null: per-sample bias (sample = m / rows_per_sample)
+    const bf16_t* res;       // [M, ldr] or null
+    long long ldx, ldy, ldr, x_bytes;
+    int sbias_ld, rows_per_sample;
+    int M, Cout, Cin, T, H, W, Ho, Wo;
+    int KT, KH, KW, pt, ph, pw, stride;
+};
+
+#define CN_BM 128
+#define CN_BN 128
+#define CN_BK 64
+#define CN_CS_LD 132
+#define CN_OOB 0x80000000u
+
+__global__ __launch_bounds__(256, 2) void convnd_cl_kernel(ConvNdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nbm = (p.M + CN_BM - 1) / CN_BM, nbn = (p.Cout + CN_BN - 1) / CN_BN;
+    const int id = xcd_remap(blockIdx.x, nbm * nbn);
+    const int tile_m = id / nbn, tile_n = id % nbn;
+    const int row0 = tile_m * CN_BM, col0 = tile_n * CN_BN;
+    const int HWo = p.Ho * p.Wo;
+    const int ldw = p.KT * p.KH * p.KW * p.Cin;
+
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.x, (unsigned)p.x_bytes);
+    const long long w_rem = (long long)(p.Cout - col0) * ldw * 2;
+    __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w + (size_t)col0 * ldw, (unsigned)(w_rem > 0x7fffffffLL ? 0x7fffffffLL : w_rem));
+
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int drl = lane >> 3, dcp = lane & 7;
+    const int chunk_off = (dcp ^ drl) << 4;
+    int w_voff[4];
+    int rt[4], rh[4], rw_[4], rn[4];     // (t, ho, wo, n) of this lane's four output rows; rt < 0: row beyond M
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drl;
+        w_voff[j] = row * ldw * 2 + chunk_off;
+        const int m = row0 + row;
+        if (m < p.M) {
+            const int sp = m % HWo;
+            const int nt = m / HWo;
+            rt[j] = nt % p.T; rn[j] = nt / p.T;
+            rh[j] = sp / p.Wo;
+            rw_[j] = sp - rh[j] * p.Wo;
+        } else {
+            rt[j] = -1; rh[j] = 0; rw_[j] = 0; rn[j] = 0;
+        }
+    }
+    const int kpt = p.Cin / CN_BK;
+    const int ntaps = p.KT * p.KH * p.KW;
+    unsigned a_voff[4];
+    auto set_tap = [&](int tap) {
+        const int dw = tap % p.KW, dh = (tap / p.KW) % p.KH, dt = tap / (p.KW * p.KH);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tt = rt[j] + dt - p.pt;
+            const int hh = rh[j] * p.stride + dh - p.ph, ww = rw_[j] * p.stride + dw - p.pw;
+            const bool ok = rt[j] >= 0 && tt >= 0 && tt < p.T && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+            const long long r = (((long long)rn[j] * p.T + tt) * p.H + hh) * p.W + ww;
+            a_voff[j] = ok ? (unsigned)(r * p.ldx * 2 + chunk_off) : CN_OOB;
+        }
+    };
+    int d_tap = 0, d_kc = 0;
+    auto dma = [&](int buf) {
+        if (d_kc == 0) set_tap(d_tap);
+        const int a_soff = d_kc * CN_BK * 2;
+        const int w_soff = (d_tap * p.Cin + d_kc * CN_BK) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* dst = smem + buf * 32768 + (wv + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, (int)a_voff[j], a_soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + 16384), 16, w_voff[j], w_soff, 0, 0);
+        }
+        if (++d_kc == kpt) { d_kc = 0; ++d_tap; }
+    };
+
+    f32x4 acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = ntaps * kpt;
+    dma(0);
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) dma(buf ^ 1);
+        const char* As = smem + buf * 32768;
+        const char* Ws = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = (((ks * 4 + fq) ^ fx) << 4);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(As + (wm * 64 + t * 16 + frow) * 128 + coff);
+                wf[t] = *(const bf16x8*)(Ws + (wn * 64 + t * 16 + frow) * 128 + coff);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: two 64-row halves through LDS; bias + per-sample bias + residual; bf16 store ----------------
+    float* Cs = (float*)smem;
+    const int er = tid >> 5, ec = (tid & 31) * 4;
+    const int n = col0 + ec;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && n < p.Cout) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias4[j] = bf2f(p.bias[n + j]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    *(f32x4*)(Cs + (tm * 16 + frow) * CN_CS_LD + wn * 64 + tn * 16 + fq * 4) = acc[tn][tm];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int ml = pass * 8 + er;
+            const int m = row0 + half * 64 + ml;
+            if (m < p.M && n < p.Cout) {
+                f32x4 v = *(const f32x4*)(Cs + ml * CN_CS_LD + ec);
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = v[j] + bias4[j];
+                if (p.sbias != nullptr) {
+                    const f32x4 sb = *(const f32x4*)(p.sbias + (size_t)(m / p.rows_per_sample) * p.sbias_ld + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += sb[j];
+                }
+                if (p.res != nullptr) {
+                    const u32x2 r2 = *(const u32x2*)(p.res + (size_t)m * p.ldr + n);
+                    o[0] += __uint_as_float(r2[0] << 16); o[1] += __uint_as_float(r2[0] & 0xffff0000u);
+                    o[2] += __uint_as_float(r2[1] << 16); o[3] += __uint_as_float(r2[1] & 0xffff0000u);
+                }
+                u32x2 c2;
+                c2[0] = pack2(o[0], o[1]);
+                c2[1] = pack2(o[2], o[3]);
+                *(u32x2*)(p.y + (size_t)m * p.ldy + n) = c2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// x: bf16 [N,T,H,W,Cin] (position stride ldx), wk: bf16 [Cout, KT*KH*KW*Cin] tap-major (dt,dh,dw,ci); y: bf16
+// [N,T,Ho,Wo,Cout] with Ho = (H + 2 ph - KH) / stride + 1 (same for W); bias bf16 [Cout] | null; sbias fp32 [N, sbias_ld] | null;
+// res bf16 like y | null.  Cin % 64 == 0, Cout % 4 == 0, the whole x must span < 2 GiB.
+extern "C" int vt_conv_cl(const void* x, long long ldx, const void* wk, const void* bias, const float* sbias, int sbias_ld,
+                          const void* res, long long ldr, void* y, long long ldy,
+                          int N, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int pt, int ph, int pw, int stride,
+                          void* stream) {
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin % CN_BK) || (Cout % 4)) return VT_ERR_BAD_SHAPE;
+    if (KT < 1 || KH < 1 || KW < 1 || stride < 1 || pt < 0 || ph < 0 || pw < 0 || 2 * pt != KT - 1) return VT_ERR_BAD_SHAPE;   // no temporal stride / shrink
+    const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return VT_ERR_BAD_SHAPE;
+    if ((ldx % 8) || (ldy % 4) || ldx < Cin || ldy < Cout || (res != nullptr && ((ldr % 4) || ldr < Cout))) return VT_ERR_BAD_SHAPE;
+    if (sbias != nullptr && ((sbias_ld % 4) || sbias_ld < Cout)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)sbias)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
+    const long long xb = rows_in * ldx * 2;
+    if (xb >= 0x7fffffffLL || rows_out >= 0x7fffffffLL || (long long)KT * KH * KW * Cin * 2 * CN_BN >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
+    ConvNdParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)wk; p.y = (bf16_t*)y; p.bias = (const bf16_t*)bias; p.sbias = sbias;
+    p.res = (const bf16_t*)res; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.x_bytes = xb; p.sbias_ld = sbias_ld;
+    p.rows_per_sample = T * Ho * Wo;
+    p.M = (int)rows_out; p.Cout = Cout; p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+    p.KT = KT; p.KH = KH; p.KW = KW; p.pt = pt; p.ph = ph; p.pw = pw; p.stride = stride;
+    const int nbm = (p.M + CN_BM - 1) / CN_BM, nbn = (Cout + CN_BN - 1) / CN_BN;
+    hipLaunchKernelGGL(convnd_cl_kernel, dim3(nbm * nbn), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[co, tap, ci] (+)= sum_m dY[m, co] * x[shift(m, tap), ci]      (fp32, laid out like wk: [Cout, taps*Cin])
+// The reduction runs over the output positions m -- the slow index of both operands -- so, as in gemm_nt_bf16.hip, tiles are staged
+// row-major ([64 positions][128 channels], LDS-DMA, source-side swizzle) and both MFMA fragments come from transposed LDS reads
+// (ds_read_b64_tr_b16); the x rows of a K-tile are GATHERED: row m of the tile is the input position that tap (blockIdx.z) pairs
+// with output position m, or zeros.  P = Cout and Q = Cin need not be tile multiples: the columns past them hold whatever lies
+// next in memory, feed only accumulators that are never stored.  The position axis is split over blockIdx.y (fp32 atomics) until the
+// grid fills the chip.  With one tap and no shift this is also the weight gradient of an nn.Linear whose dimensions are not
+// multiples of 128 (C = 320).
+struct ConvDwParams {
+    const bf16_t* dy; const bf16_t* x; float* dw;
+    long long lddy, ldx, dy_bytes, x_bytes;
+    int M, Cout, Cin, T, H, W, Ho, Wo, KT, KH, KW, pt, ph, pw, stride;
+    int m_chunk, splits, accumulate;
+};
+typedef __attribute__((ext_vector_type(8))) short short8cn;
+__device__ __forceinline__ int cn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ bf16x8 cn_tr_pair(const char* p0, const char* p1) {
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(p0));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(p1));
+    short8cn v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v8);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int nbp = (p.Cout + 127) / 128, nbq = (p.Cin + 127) / 128;
+    const int id = xcd_remap(blockIdx.x, nbp * nbq);
+    const int tile_p = id % nbp, tile_q = id / nbp;
+    const int p0 = tile_p * 128, q0 = tile_q * 128;
+    const int tap = blockIdx.z;
+    const int dw_ = tap % p.KW, dh = (tap / p.KW) % p.KH, dt = tap / (p.KW * p.KH);
+    const int ntaps = p.KT * p.KH * p.KW;
+    const int HWo = p.Ho * p.Wo;
+
+    const int m_lo = (int)blockIdx.y * p.m_chunk;
+    const int m_cnt = min(p.M - m_lo, p.m_chunk);
+    if (m_cnt <= 0) return;
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.dy, (unsigned)p.dy_bytes);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.x, (unsigned)p.x_bytes);
+
+    const int drl = lane >> 4, dcp = lane & 15;
+    auto dma = [&](int kt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * (wave + 4 * j) + drl;
+            const int ch = dcp ^ cn_swz(row);
+            const int ml = kt * 64 + row;
+            const int m = m_lo + ml;
+            unsigned a_off = CN_OOB, b_off = CN_OOB;
+            if (ml < m_cnt) {
+                a_off = (unsigned)((long long)m * p.lddy * 2 + (p0 + ch * 8) * 2);
+                const int sp = m % HWo, nt = m / HWo;
+                const int t = nt % p.T, n = nt / p.T;
+                const int ho = sp / p.Wo, wo = sp - ho * p.Wo;
+                const int tt = t + dt - p.pt, hh = ho * p.stride + dh - p.ph, ww = wo * p.stride + dw_ - p.pw;
+                if (tt >= 0 && tt < p.T && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
+                    const long long r = (((long long)n * p.T + tt) * p.H + hh) * p.W + ww;
+                    b_off = (unsigned)(r * p.ldx * 2 + (q0 + ch * 8) * 2);
+                }
+            }
+            char* dst = smem + buf * 32768 + (wave + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, (int)a_off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst + 16384), 16, (int)b_off, 0, 0, 0);
+        }
+    };
+    const int g = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
+    auto tr_addr = [&](const char* img, int slab_col0, int ks, int sec, int t) {
+        const int row = ks * 32 + 8 * g + ql + 4 * sec;
+        const int col = slab_col0 + t * 16 + 4 * pl;
+        return img + row * 256 + (((col >> 3) ^ cn_swz(row)) << 4) + (col & 7) * 2;
+    };
+    f32x4 acc[4][4];     // [tp][tq]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (m_cnt + 63) / 64;
+    dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+        const char* As = smem + buf * 32768;
+        const char* Bs = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = cn_tr_pair(tr_addr(As, wp * 64, ks, 0, t), tr_addr(As, wp * 64, ks, 1, t));
+                bfr[t] = cn_tr_pair(tr_addr(Bs, wq * 64, ks, 0, t), tr_addr(Bs, wq * 64, ks, 1, t));
+            }
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq)
+                    acc[tp][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tp], bfr[tq], acc[tp][tq], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int fr = lane & 15;
+    const long long ldc = (long long)ntaps * p.Cin;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int pr = p0 + wp * 64 + tp * 16 + 4 * g + rg;
+                const int qc = q0 + wq * 64 + tq * 16 + fr;
+                if (pr < p.Cout && qc < p.Cin) {
+                    float* c = p.dw + (size_t)pr * ldc + (size_t)tap * p.Cin + qc;
+                    const float v = acc[tp][tq][rg];
+                    if (p.splits > 1 || p.accumulate) atomicAdd(c, v);
+                    else *c = v;
+                }
+            }
+}
+
+// dy: bf16 [N,T,Ho,Wo,Cout] (position stride lddy), x: bf16 [N,T,H,W,Cin] (ldx), dw: fp32 [Cout, taps*Cin].  accumulate != 0: dw +=
+// (gradient accumulation over micro-batches); otherwise dw is overwritten.  ldx % 8 == 0, lddy % 8 == 0 (16-byte rows; Cin / Cout themselves
+// are free: 4 output channels live in an 8-wide buffer), both tensors < 2 GiB.
+extern "C" int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long long ldx, float* dw,
+                             int N, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int pt, int ph, int pw, int stride,
+                             int accumulate, void* stream) {
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VT_ERR_BAD_SHAPE;
+    if (KT < 1 || KH < 1 || KW < 1 || stride < 1 || pt < 0 || ph < 0 || pw < 0 || 2 * pt != KT - 1) return VT_ERR_BAD_SHAPE;
+    const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0 || (ldx % 8) || (lddy % 8) || ldx < Cin || lddy < Cout) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)dy)) & 15 || (((uintptr_t)dw) & 3)) return VT_ERR_BAD_ALIGN;
+    const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
+    // + 256 bytes of slack: a ragged last column tile reads up to 254 bytes past the last row (zeros beyond the descriptor)
+    const long long xb = rows_in * ldx * 2, yb = rows_out * lddy * 2;
+    if (xb >= 0x7fffff00LL || yb >= 0x7fffff00LL) return VT_ERR_BAD_SHAPE;
+    ConvDwParams p;
+    p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.lddy = lddy; p.ldx = ldx; p.dy_bytes = yb; p.x_bytes = xb;
+    p.M = (int)rows_out; p.Cout = Cout; p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+    p.KT = KT; p.KH = KH; p.KW = KW; p.pt = pt; p.ph = ph; p.pw = pw; p.stride = stride; p.accumulate = accumulate;
+    const int taps = KT * KH * KW;
+    const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    long long want = (2LL * cus + (long long)tiles * taps - 1) / ((long long)tiles * taps);       // ~2 workgroups per CU
+    long long maxs = (rows_out + 511) / 512;                                                       // >= 8 K-tiles per workgroup
+    int splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+    if (splits < 1) splits = 1;
+    int chunk = (int)((rows_out + splits - 1) / splits);
+    chunk = (chunk + 63) / 64 * 64;
+    splits = (int)((rows_out + chunk - 1) / chunk);
+    p.m_chunk = chunk; p.splits = splits;
+    hipStream_t st = (hipStream_t)stream;
+    if (splits > 1 && !accumulate) {
+        if (hipMemsetAsync(dw, 0, (size_t)Cout * taps * Cin * 4, st) != hipSuccess) return VT_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(conv_dw_kernel, dim3(tiles, splits, taps), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

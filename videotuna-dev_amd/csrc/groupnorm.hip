@@ -20,25 +20,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* x, l
     extern __shared__ float red[];                 // [2][C]
     const int n = blockIdx.y, slab = blockIdx.x;
     const int nch = C >> 3;                        // 16-byte chunks per position
-    const int lanes = GN_THREADS / nch * nch;      // threads that take part (a whole number of positions per pass)
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * C; i += GN_THREADS) red[i] = 0.f;
     __syncthreads();
     const long long p0 = P * slab / slabs, p1 = P * (slab + 1) / slabs;
-    if (tid < lanes) {
-        const int c = tid % nch, row = tid / nch, rows = lanes / nch;
-        float s[8], q[8];
+    for (int c0 = 0; c0 < nch; c0 += GN_THREADS) {       // more than 2048 channels (the UNet's 2560-wide skip concatenations): channel passes
+        const int ncl = min(nch - c0, GN_THREADS);
+        const int lanes = GN_THREADS / ncl * ncl;         // threads that take part (a whole number of positions per pass)
+        if (tid < lanes) {
+            const int c = c0 + tid % ncl, row = tid / ncl, rows = lanes / ncl;
+            float s[8], q[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-        const bf16_t* xb = x + ((long long)n * P) * ldx + c * 8;
-        for (long long p = p0 + row; p < p1; p += rows) {
-            float v[8];
-            unpack8(*(const u32x4*)(xb + p * ldx), v);
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+            const bf16_t* xb = x + ((long long)n * P) * ldx + c * 8;
+            for (long long p = p0 + row; p < p1; p += rows) {
+                float v[8];
+                unpack8(*(const u32x4*)(xb + p * ldx), v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+                for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(red + c * 8 + j, s[j]); atomicAdd(red + C + c * 8 + j, q[j]); }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { atomicAdd(red + c * 8 + j, s[j]); atomicAdd(red + C + c * 8 + j, q[j]); }
     }
     __syncthreads();
     float* w = ws + (size_t)n * 4 * C;
@@ -61,6 +64,8 @@ __global__ void gn_finalize_kernel(float* ws, const bf16_t* gamma, const bf16_t*
             const float ga = gamma ? bf2f(gamma[c]) : 1.f, be = beta ? bf2f(beta[c]) : 0.f;
             w[2 * C + c] = rstd * ga;
             w[3 * C + c] = be - mean * rstd * ga;
+            w[c] = mean;          // the sums are spent: the first two planes keep the statistics for vt_groupnorm_silu_bwd_cl
+            w[C + c] = rstd;
         }
     }
 }
@@ -95,7 +100,7 @@ extern "C" long long vt_groupnorm_ws_bytes(int N, int C) { return (long long)N *
 // vt_groupnorm_ws_bytes(N, C) bytes (contents don't matter).  silu != 0 applies x*sigmoid(x) to the normalised value.
 extern "C" int vt_groupnorm_silu_cl(const void* x, long long ldx, const void* gamma, const void* beta, void* y, long long ldy,
                                     int N, long long P, int C, int G, float eps, int silu, float* ws, long long ws_bytes, void* stream) {
-    if (N <= 0 || P <= 0 || C <= 0 || G <= 0 || (C % G) || (C % 8) || C > 8 * GN_THREADS || (ldx % 8) || (ldy % 8) || ldx < C || ldy < C)
+    if (N <= 0 || P <= 0 || C <= 0 || G <= 0 || (C % G) || (C % 8) || C > 8192 || (ldx % 8) || (ldy % 8) || ldx < C || ldy < C)
         return VT_ERR_BAD_SHAPE;
     if (N > 65535 || ws == nullptr || ws_bytes < vt_groupnorm_ws_bytes(N, C)) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return VT_ERR_BAD_ALIGN;

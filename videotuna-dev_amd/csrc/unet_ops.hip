@@ -1,0 +1,345 @@
+// Memory-bound kernels of the VideoCrafter2 UNet path (BASELINE configs[3]) on ONE channels-last layout
+// [N, P, C] / [B, T, H, W, C] (bf16 activations, fp32 statistics and parameter gradients):
+//   GroupNorm backward (+ the SiLU that follows it) .. GroupNormSpecific -> SiLU of ResBlock / TemporalConvBlock / out, the plain
+//                                                      GroupNorm of Spatial/TemporalTransformer.norm
+//                                                      (lvdm/modules/networks/openaimodel3d.py:229-255, 278-296, 643-648;
+//                                                       lvdm/modules/attention.py:337-339, 421-423; utils.py:192-203)
+//   GEGLU forward / backward ......................... attention.py:522-529  (x * gelu(gate), exact erf GELU)
+//   frame <-> pixel row transposes ................... the `b c t h w -> (b h w) t c` rearranges of TemporalTransformer.forward
+//                                                      (attention.py:476-481, 509-516) as ONE row permutation each way
+//   nearest x2 upsample forward / backward ........... Upsample.forward (openaimodel3d.py:112-120)
+//   zero insertion ................................... input gradient of Downsample.op (stride-2 conv, :71-79): dX = conv(stride 1) of
+//                                                      the zero-upsampled dY with the flipped weight
+//   row add .......................................... gradient accumulation where a tensor feeds two consumers (residuals, skips)
+//   eps-prediction MSE loss forward / backward ....... LVDMFlow.p_losses (lvdm/ddpm3d.py:787-847), q_sample (schedulers/ddpm.py:216-222)
+// All HBM-bound, one read + one write of each operand unless noted.
+#include "common.h"
+
+#define UO_THREADS 256
+
+__device__ __forceinline__ float silu_sig(float g) { return 1.0f - __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(g * 1.4426950408889634f) + 1.0f); }
+
+// ----------------------------------------------------------------------------------------------------------------- GroupNorm backward
+// forward (groupnorm.hip): g = x * a[n,c] + b[n,c], y = SILU ? g * sigmoid(g) : g; ws_fwd = [N][4][C]: mean_c | rstd_c | a | b.
+// backward: dg = dy * (SILU ? s (1 + g (1 - s)) : 1);  xh = (x - mean) rstd
+//   S1[n,c] = sum_p dg, S2[n,c] = sum_p dg * xh              (pass 1, per-channel, fp32 atomics into ws_bwd [N][4][C])
+//   dgamma[c] += sum_n S2, dbeta[c] += sum_n S1;  per group: A = sum_c gamma S2, Bs = sum_c gamma S1, cnt = P * C/G
+//   dx = dg * a + x * k2 + k3,   k2 = -rstd^2 A / cnt,  k3 = -rstd Bs / cnt - mean k2       (pass 2: finalize, pass 3: apply)
+template <bool SILU>
+__global__ __launch_bounds__(UO_THREADS) void gn_bwd_stats_kernel(const bf16_t* dy, long long lddy, const bf16_t* x, long long ldx, long long P,
+                                                                 int C, const float* wsf, float* wsb, int slabs) {
+    extern __shared__ float red[];                 // [2][C]
+    const int n = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const int nch = C >> 3;
+    for (int i = tid; i < 2 * C; i += UO_THREADS) red[i] = 0.f;
+    __syncthreads();
+    const float* wf = wsf + (size_t)n * 4 * C;
+    const long long p0 = P * slab / slabs, p1 = P * (slab + 1) / slabs;
+    for (int c0 = 0; c0 < nch; c0 += UO_THREADS) {
+        const int ncl = min(nch - c0, UO_THREADS);
+        const int lanes = UO_THREADS / ncl * ncl;
+        if (tid < lanes) {
+            const int c = c0 + tid % ncl, row = tid / ncl, rows = lanes / ncl;
+            float mean[8], rstd[8], a[8], b[8], s1[8], s2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mean[j] = wf[c * 8 + j]; rstd[j] = wf[C + c * 8 + j]; a[j] = wf[2 * C + c * 8 + j]; b[j] = wf[3 * C + c * 8 + j];
+                s1[j] = 0.f; s2[j] = 0.f;
+            }
+            for (long long p = p0 + row; p < p1; p += rows) {
+                float xv[8], dv[8];
+                unpack8(*(const u32x4*)(x + ((long long)n * P + p) * ldx + c * 8), xv);
+                unpack8(*(const u32x4*)(dy + ((long long)n * P + p) * lddy + c * 8), dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float dg = dv[j];
+                    if (SILU) {
+                        const float g = xv[j] * a[j] + b[j];
+                        const float s = silu_sig(g);
+                        dg *= s * (1.0f + g * (1.0f - s));
+                    }
+                    s1[j] += dg;
+                    s2[j] += dg * (xv[j] - mean[j]) * rstd[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(red + c * 8 + j, s1[j]); atomicAdd(red + C + c * 8 + j, s2[j]); }
+        }
+    }
+    __syncthreads();
+    float* w = wsb + (size_t)n * 4 * C;
+    for (int i = tid; i < 2 * C; i += UO_THREADS) atomicAdd(w + i, red[i]);
+}
+
+__global__ void gn_bwd_finalize_kernel(const float* wsf, float* wsb, const bf16_t* gamma, float* dgamma, float* dbeta, long long P, int C, int G) {
+    const int n = blockIdx.x;
+    const float* wf = wsf + (size_t)n * 4 * C;
+    float* w = wsb + (size_t)n * 4 * C;
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float A = 0.f, Bs = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+            const int c = g * cpg + j;
+            const float ga = gamma ? bf2f(gamma[c]) : 1.f;
+            A += ga * w[C + c]; Bs += ga * w[c];
+            if (dgamma) atomicAdd(dgamma + c, w[C + c]);
+            if (dbeta) atomicAdd(dbeta + c, w[c]);
+        }
+        const float cnt = (float)cpg * (float)P;
+        const float mean = wf[g * cpg], rstd = wf[C + g * cpg];
+        const float k2 = -rstd * rstd * A / cnt;
+        const float k3 = -rstd * Bs / cnt - mean * k2;
+        for (int j = 0; j < cpg; ++j) { w[2 * C + g * cpg + j] = k2; w[3 * C + g * cpg + j] = k3; }
+    }
+}
+
+template <bool SILU, bool ACC>
+__global__ __launch_bounds__(UO_THREADS) void gn_bwd_apply_kernel(const bf16_t* dy, long long lddy, const bf16_t* x, long long ldx, bf16_t* dx,
+                                                                 long long lddx, long long P, int C, const float* wsf, const float* wsb) {
+    const int n = blockIdx.y;
+    const int nch = C >> 3;
+    const float* a = wsf + (size_t)n * 4 * C + 2 * C;
+    const float* b = a + C;
+    const float* k2 = wsb + (size_t)n * 4 * C + 2 * C;
+    const float* k3 = k2 + C;
+    const long long total = P * nch;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const long long p = i / nch;
+        const int c = (int)(i - p * nch) * 8;
+        float xv[8], dv[8], o[8];
+        unpack8(*(const u32x4*)(x + ((long long)n * P + p) * ldx + c), xv);
+        unpack8(*(const u32x4*)(dy + ((long long)n * P + p) * lddy + c), dv);
+        if (ACC) unpack8(*(const u32x4*)(dx + ((long long)n * P + p) * lddx + c), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dg = dv[j];
+            const float aj = a[c + j];
+            if (SILU) {
+                const float g = xv[j] * aj + b[c + j];
+                const float s = silu_sig(g);
+                dg *= s * (1.0f + g * (1.0f - s));
+            }
+            const float r = dg * aj + xv[j] * k2[c + j] + k3[c + j];
+            o[j] = ACC ? o[j] + r : r;
+        }
+        *(u32x4*)(dx + ((long long)n * P + p) * lddx + c) = pack8(o);
+    }
+}
+
+// dy, x: bf16 [N, P, C]; ws_fwd: the forward call's workspace (vt_groupnorm_silu_cl leaves mean | rstd | a | b per (n, c) in it);
+// ws_bwd: fp32 scratch of vt_groupnorm_ws_bytes(N, C) bytes; dgamma / dbeta: fp32 [C], ACCUMULATED (or null); dx: bf16 [N, P, C],
+// overwritten, or added to when accumulate != 0 (the tensor also feeds another consumer).
+extern "C" int vt_groupnorm_silu_bwd_cl(const void* dy, long long lddy, const void* x, long long ldx, const void* gamma,
+                                        const float* ws_fwd, float* ws_bwd, long long ws_bytes, void* dx, long long lddx,
+                                        float* dgamma, float* dbeta, int N, long long P, int C, int G, int silu, int accumulate, void* stream) {
+    if (N <= 0 || P <= 0 || C <= 0 || G <= 0 || (C % G) || (C % 8) || (ldx % 8) || (lddy % 8) || (lddx % 8) || ldx < C || lddy < C || lddx < C)
+        return VT_ERR_BAD_SHAPE;
+    if (N > 65535 || ws_fwd == nullptr || ws_bwd == nullptr || ws_bytes < (long long)N * 4 * C * 4) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)ws_fwd) | ((uintptr_t)ws_bwd)) & 15) return VT_ERR_BAD_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws_bwd, 0, (size_t)N * 4 * C * 4, st) != hipSuccess) return VT_ERR_LAUNCH;
+    long long want = (P * N + 255) / 256 / N;
+    int slabs = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    if (silu) hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(slabs, N), dim3(UO_THREADS), 2 * C * sizeof(float), st, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, P, C, ws_fwd, ws_bwd, slabs);
+    else hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(slabs, N), dim3(UO_THREADS), 2 * C * sizeof(float), st, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, P, C, ws_fwd, ws_bwd, slabs);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(64), 0, st, ws_fwd, ws_bwd, (const bf16_t*)gamma, dgamma, dbeta, P, C, G);
+    const long long total = P * (C >> 3);
+    long long blocks = (total + UO_THREADS - 1) / UO_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks, N);
+#define GNB(S, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<S, A>), grid, dim3(UO_THREADS), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, P, C, ws_fwd, ws_bwd)
+    if (silu) { if (accumulate) GNB(true, true); else GNB(true, false); }
+    else { if (accumulate) GNB(false, true); else GNB(false, false); }
+#undef GNB
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- GEGLU
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// h: [M, 2F] = (a | gate) from GEGLU.proj; y[m, f] = a * gelu(gate)
+__global__ __launch_bounds__(UO_THREADS) void geglu_fwd_kernel(const bf16_t* h, long long ldh, bf16_t* y, long long ldy, long long M, int F) {
+    const int nch = F >> 3;
+    const long long total = M * nch;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch) * 8;
+        float a[8], g[8];
+        unpack8(*(const u32x4*)(h + m * ldh + c), a);
+        unpack8(*(const u32x4*)(h + m * ldh + F + c), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= gelu_erf_f(g[j]);
+        *(u32x4*)(y + m * ldy + c) = pack8(a);
+    }
+}
+__global__ __launch_bounds__(UO_THREADS) void geglu_bwd_kernel(const bf16_t* dy, long long lddy, const bf16_t* h, long long ldh, bf16_t* dh, long long lddh,
+                                                              long long M, int F) {
+    const int nch = F >> 3;
+    const long long total = M * nch;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch) * 8;
+        float a[8], g[8], d[8], da[8], dg[8];
+        unpack8(*(const u32x4*)(h + m * ldh + c), a);
+        unpack8(*(const u32x4*)(h + m * ldh + F + c), g);
+        unpack8(*(const u32x4*)(dy + m * lddy + c), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { da[j] = d[j] * gelu_erf_f(g[j]); dg[j] = d[j] * a[j] * gelu_erf_grad_f(g[j]); }
+        *(u32x4*)(dh + m * lddh + c) = pack8(da);
+        *(u32x4*)(dh + m * lddh + F + c) = pack8(dg);
+    }
+}
+static unsigned uo_blocks(long long total) { long long b = (total + UO_THREADS - 1) / UO_THREADS; return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+extern "C" int vt_geglu_fwd(const void* h, long long ldh, void* y, long long ldy, long long M, int F, void* stream) {
+    if (M <= 0 || F <= 0 || (F % 8) || (ldh % 8) || (ldy % 8) || ldh < 2 * F || ldy < F) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)h) | ((uintptr_t)y)) & 15) return VT_ERR_BAD_ALIGN;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(uo_blocks(M * (F >> 3))), dim3(UO_THREADS), 0, (hipStream_t)stream, (const bf16_t*)h, ldh, (bf16_t*)y, ldy, M, F);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+extern "C" int vt_geglu_bwd(const void* dy, long long lddy, const void* h, long long ldh, void* dh, long long lddh, long long M, int F, void* stream) {
+    if (M <= 0 || F <= 0 || (F % 8) || (ldh % 8) || (lddy % 8) || (lddh % 8) || ldh < 2 * F || lddh < 2 * F || lddy < F) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)h) | ((uintptr_t)dy) | ((uintptr_t)dh)) & 15) return VT_ERR_BAD_ALIGN;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(uo_blocks(M * (F >> 3))), dim3(UO_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)h, ldh,
+                       (bf16_t*)dh, lddh, M, F);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- row-wise helpers
+// out[m, :] = a[m, :] + b[m, :]   (b may alias out)
+__global__ __launch_bounds__(UO_THREADS) void add_rows_kernel(const bf16_t* a, long long lda, const bf16_t* b, long long ldb, bf16_t* o, long long ldo,
+                                                             long long M, int C) {
+    const int nch = C >> 3;
+    const long long total = M * nch;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch) * 8;
+        float x[8], y[8];
+        unpack8(*(const u32x4*)(a + m * lda + c), x);
+        unpack8(*(const u32x4*)(b + m * ldb + c), y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        *(u32x4*)(o + m * ldo + c) = pack8(x);
+    }
+}
+extern "C" int vt_add_rows_bf16(const void* a, long long lda, const void* b, long long ldb, void* out, long long ldo, long long M, int C, void* stream) {
+    if (M <= 0 || C <= 0 || (C % 8) || (lda % 8) || (ldb % 8) || (ldo % 8) || lda < C || ldb < C || ldo < C) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) return VT_ERR_BAD_ALIGN;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(uo_blocks(M * (C >> 3))), dim3(UO_THREADS), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       (bf16_t*)out, ldo, M, C);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// Row gather with an optional add: out[m, :] (+)= src[map(m), :].  MODE 0: [B, A1, A2, C] -> [B, A2, A1, C] (the frame <-> pixel transpose
+// of TemporalTransformer, its own inverse with A1 / A2 swapped); MODE 1: nearest x2 upsample [N, H, W] -> [N, 2H, 2W]; MODE 2: zero
+// insertion [N, H, W] -> [N, 2H, 2W] (value at even positions, zeros elsewhere); MODE 3: sum of the 2x2 block [N, 2H, 2W] -> [N, H, W]
+// (backward of MODE 1).
+template <int MODE>
+__global__ __launch_bounds__(UO_THREADS) void row_map_kernel(const bf16_t* src, long long lds_, bf16_t* out, long long ldo, long long Mo, int C,
+                                                            int d1, int d2, int accumulate) {
+    const int nch = C >> 3;
+    const long long total = Mo * nch;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const long long m = i / nch;
+        const int c = (int)(i - m * nch) * 8;
+        float v[8];
+        if (MODE == 0) {            // out row (b, a2, a1) <- src row (b, a1, a2); d1 = A1, d2 = A2
+            const long long b = m / ((long long)d1 * d2);
+            const long long r = m - b * d1 * d2;
+            const long long a2 = r / d1, a1 = r - a2 * d1;
+            unpack8(*(const u32x4*)(src + ((b * d1 + a1) * d2 + a2) * lds_ + c), v);
+        } else if (MODE == 1 || MODE == 2) {       // out [N, 2H, 2W]; d1 = H, d2 = W of the source
+            const long long n = m / (4LL * d1 * d2);
+            const long long r = m - n * 4LL * d1 * d2;
+            const int ho = (int)(r / (2 * d2)), wo = (int)(r - (long long)ho * 2 * d2);
+            if (MODE == 1 || ((ho & 1) == 0 && (wo & 1) == 0)) unpack8(*(const u32x4*)(src + ((n * d1 + (ho >> 1)) * d2 + (wo >> 1)) * lds_ + c), v);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+        } else {                    // MODE 3: out [N, H, W] <- sum of src [N, 2H, 2W] blocks; d1 = H, d2 = W of the OUTPUT
+            const long long n = m / ((long long)d1 * d2);
+            const long long r = m - n * (long long)d1 * d2;
+            const int h = (int)(r / d2), w = (int)(r - (long long)h * d2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t[8];
+                unpack8(*(const u32x4*)(src + ((n * 2 * d1 + 2 * h + (q >> 1)) * 2 * d2 + 2 * w + (q & 1)) * lds_ + c), t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += t[j];
+            }
+        }
+        if (accumulate) {
+            float o[8];
+            unpack8(*(const u32x4*)(out + m * ldo + c), o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        *(u32x4*)(out + m * ldo + c) = pack8(v);
+    }
+}
+// mode 0: src [B, d1, d2, C] -> out [B, d2, d1, C] (Mo = B*d1*d2); 1: nearest x2, src [N, d1, d2, C] -> out [N, 2 d1, 2 d2, C];
+// 2: zero insertion, same shapes as 1; 3: 2x2 block sum, src [N, 2 d1, 2 d2, C] -> out [N, d1, d2, C].  nb = B or N.
+extern "C" int vt_row_map_bf16(const void* src, long long lds_, void* out, long long ldo, int mode, long long nb, int d1, int d2, int C,
+                               int accumulate, void* stream) {
+    if (nb <= 0 || d1 <= 0 || d2 <= 0 || C <= 0 || (C % 8) || (lds_ % 8) || (ldo % 8) || lds_ < C || ldo < C || mode < 0 || mode > 3) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)src) | ((uintptr_t)out)) & 15) return VT_ERR_BAD_ALIGN;
+    const long long Mo = (mode == 1 || mode == 2) ? nb * 4LL * d1 * d2 : nb * (long long)d1 * d2;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(uo_blocks(Mo * (C >> 3)));
+#define RM(MD) hipLaunchKernelGGL(row_map_kernel<MD>, grid, dim3(UO_THREADS), 0, st, (const bf16_t*)src, lds_, (bf16_t*)out, ldo, Mo, C, d1, d2, accumulate)
+    if (mode == 0) RM(0); else if (mode == 1) RM(1); else if (mode == 2) RM(2); else RM(3);
+#undef RM
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- eps-MSE loss
+// q_sample: x_t = sqrt_ab[b] * scale[b] * x0 + sqrt_1mab[b] * noise  (fp32 in, bf16 out; scale = scale_arr[t], ddpm3d.py:740-741, or null)
+__global__ __launch_bounds__(UO_THREADS) void q_sample_kernel(const float* x0, const float* noise, const float* sa, const float* sb, const float* scale,
+                                                             bf16_t* xt, long long per, int B) {
+    const long long total = per * B;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const int b = (int)(i / per);
+        const float s = scale ? scale[b] : 1.0f;
+        xt[i] = f2bf(sa[b] * s * x0[i] + sb[b] * noise[i]);
+    }
+}
+extern "C" int vt_q_sample(const float* x0, const float* noise, const float* sqrt_ab, const float* sqrt_1mab, const float* scale, void* xt,
+                           long long per_sample, int B, void* stream) {
+    if (per_sample <= 0 || B <= 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(uo_blocks(per_sample * B)), dim3(UO_THREADS), 0, (hipStream_t)stream, x0, noise, sqrt_ab, sqrt_1mab, scale,
+                       (bf16_t*)xt, per_sample, B);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+// loss = mean_b mean_i (pred - target)^2 ; dpred = 2 (pred - target) / (per * B) * gscale   (pred bf16, target fp32)
+__global__ __launch_bounds__(UO_THREADS) void mse_loss_kernel(const bf16_t* pred, const float* target, float* loss, bf16_t* dpred, long long total,
+                                                             float inv, float gscale) {
+    __shared__ float red[UO_THREADS / 64];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const float d = bf2f(pred[i]) - target[i];
+        acc += d * d;
+        if (dpred) dpred[i] = f2bf(2.0f * d * inv * gscale);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < UO_THREADS / 64; ++i) s += red[i];
+        atomicAdd(loss, s * inv);
+    }
+}
+// loss: fp32 [1], zeroed by the call; dpred (bf16, optional) = d loss / d pred * grad_scale
+extern "C" int vt_mse_loss(const void* pred, const float* target, float* loss, void* dpred, long long total, float grad_scale, void* stream) {
+    if (total <= 0) return VT_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, 4, st) != hipSuccess) return VT_ERR_LAUNCH;
+    long long b = (total + UO_THREADS - 1) / UO_THREADS;
+    hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(UO_THREADS), 0, st, (const bf16_t*)pred, target, loss, (bf16_t*)dpred, total,
+                       1.0f / (float)total, grad_scale);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

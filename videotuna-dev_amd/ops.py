@@ -558,3 +558,167 @@ def lora_pack_b(bcat_f32, wext, ldw: int, n_adapters: int, d_out: int, r: int, s
 def lora_pack_bt(bcat_f32, wtext, ldwt: int, n_adapters: int, d_out: int, r: int, scale: float):
     check(load_library().vt_lora_pack_bt(bcat_f32.data_ptr(), wtext.data_ptr(), ldwt, n_adapters, d_out, r, scale, _stream()),
           "vt_lora_pack_bt")
+
+
+# =====================================================================================================================
+# VideoCrafter2 UNet path (include/vt355.h, second half): channels-last [N, T, H, W, C] activations
+# =====================================================================================================================
+def pack_conv_weight_nd(w: torch.Tensor) -> torch.Tensor:
+    """torch conv weight [Cout, Cin, *k] (Conv2d [.,.,KH,KW] or Conv3d [.,.,KT,KH,KW]) -> [Cout, taps*Cin], tap-major, ci innermost"""
+    if w.dim() == 4:
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    if w.dim() == 5:
+        return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+    raise ValueError(f"expected a 4-d or 5-d conv weight, got {tuple(w.shape)}")
+
+
+def pack_conv_weight_dx(w: torch.Tensor) -> torch.Tensor:
+    """weight of the INPUT-gradient convolution of a stride-1 'same' conv: taps flipped, in / out channels swapped:
+    [Cout, Cin, *k] -> [Cin, taps * Cout]"""
+    dims = tuple(range(2, w.dim()))
+    return pack_conv_weight_nd(w.flip(dims).transpose(0, 1))
+
+
+def conv_cl(x, wk, y, kernel, padding, stride: int = 1, bias=None, sbias=None, residual=None):
+    """x bf16 [N,T,H,W,Cin], wk bf16 [Cout, KT*KH*KW*Cin], y bf16 [N,T,Ho,Wo,Cout]; kernel = (KT,KH,KW), padding = (pt,ph,pw);
+    bias bf16 [Cout]; sbias fp32 [N, >=Cout] per-sample bias; residual like y"""
+    _req(x, BF16, "x", 5); _req(y, BF16, "y", 5); _req(wk, BF16, "wk", 2)
+    N, T, H, W, Cin = x.shape
+    Cout = y.shape[4]
+    KT, KH, KW = kernel
+    pt, ph, pw = padding
+    Ho, Wo = (H + 2 * ph - KH) // stride + 1, (W + 2 * pw - KW) // stride + 1
+    if tuple(y.shape[:4]) != (N, T, Ho, Wo) or tuple(wk.shape) != (Cout, KT * KH * KW * Cin) or not wk.is_contiguous():
+        raise ValueError(f"shape mismatch: x {tuple(x.shape)} wk {tuple(wk.shape)} y {tuple(y.shape)} (expected y {(N, T, Ho, Wo, Cout)})")
+    _cl_check(x, "x"); _cl_check(y, "y")
+    if residual is not None:
+        _req(residual, BF16, "residual", 5); _cl_check(residual, "residual")
+        if tuple(residual.shape) != tuple(y.shape):
+            raise ValueError("residual must have the shape of y")
+    if sbias is not None:
+        _req(sbias, torch.float32, "sbias", 2)
+        if sbias.shape[0] != N or sbias.shape[1] < Cout:
+            raise ValueError(f"sbias must be [N, >=Cout], got {tuple(sbias.shape)}")
+    check(load_library().vt_conv_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), _p(sbias), 0 if sbias is None else sbias.stride(0),
+                                    _p(residual), 0 if residual is None else residual.stride(3), y.data_ptr(), y.stride(3),
+                                    N, T, H, W, Cin, Cout, KT, KH, KW, pt, ph, pw, stride, _stream()), "vt_conv_cl")
+    return y
+
+
+def conv_dw_cl(dy, x, dw, kernel, padding, stride: int = 1, accumulate: bool = True):
+    """dw fp32 [Cout, taps*Cin] (+)= conv weight gradient; dy bf16 [N,T,Ho,Wo,Cout], x bf16 [N,T,H,W,Cin]"""
+    _req(x, BF16, "x", 5); _req(dy, BF16, "dy", 5); _req(dw, torch.float32, "dw", 2)
+    N, T, H, W, Cin = x.shape
+    Cout = dy.shape[4]
+    KT, KH, KW = kernel
+    pt, ph, pw = padding
+    if tuple(dw.shape) != (Cout, KT * KH * KW * Cin) or not dw.is_contiguous():
+        raise ValueError(f"dw must be contiguous [{Cout}, {KT * KH * KW * Cin}], got {tuple(dw.shape)}")
+    _cl_check(x, "x"); _cl_check(dy, "dy")
+    check(load_library().vt_conv_dw_cl(dy.data_ptr(), dy.stride(3), x.data_ptr(), x.stride(3), dw.data_ptr(), N, T, H, W, Cin, Cout,
+                                       KT, KH, KW, pt, ph, pw, stride, int(accumulate), _stream()), "vt_conv_dw_cl")
+
+
+def linear_dw(dy, x, dw, accumulate: bool = True):
+    """dw fp32 [N_out, K] (+)= dy[M, N_out]^T x[M, K] for any multiple-of-8 sizes (one-tap vt_conv_dw_cl)"""
+    _req(dy, BF16, "dy", 2); _req(x, BF16, "x", 2); _req(dw, torch.float32, "dw", 2)
+    M, P = dy.shape
+    Q = x.shape[1]
+    if x.shape[0] != M or tuple(dw.shape) != (P, Q) or not dw.is_contiguous():
+        raise ValueError(f"shape mismatch: dy {tuple(dy.shape)} x {tuple(x.shape)} dw {tuple(dw.shape)}")
+    check(load_library().vt_conv_dw_cl(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), 1, 1, 1, M, Q, P,
+                                       1, 1, 1, 0, 0, 0, 1, int(accumulate), _stream()), "vt_conv_dw_cl")
+
+
+def groupnorm_fwd(x, gamma, beta, y, groups: int, eps: float, silu: bool):
+    """like groupnorm_silu but returns the workspace (statistics) the backward needs"""
+    N, P, C = x.shape
+    ws = torch.empty(int(load_library().vt_groupnorm_ws_bytes(N, C)) // 4, dtype=torch.float32, device=x.device)
+    groupnorm_silu(x, gamma, beta, y, groups, eps, silu, ws)
+    return ws
+
+
+def groupnorm_bwd(dy, x, gamma, ws_fwd, dx, dgamma, dbeta, groups: int, silu: bool, accumulate: bool = False):
+    """dy, x, dx bf16 [N, P, C]; dgamma / dbeta fp32 [C] accumulated (or None)"""
+    _req(dy, BF16, "dy", 3); _req(x, BF16, "x", 3); _req(dx, BF16, "dx", 3)
+    N, P, C = x.shape
+    for t_, nm in ((x, "x"), (dy, "dy"), (dx, "dx")):
+        if t_.stride(0) != P * t_.stride(1):
+            raise ValueError(f"{nm}: samples must be P positions apart")
+    wsb = torch.empty_like(ws_fwd)
+    check(load_library().vt_groupnorm_silu_bwd_cl(dy.data_ptr(), dy.stride(1), x.data_ptr(), x.stride(1), _p(gamma), ws_fwd.data_ptr(),
+                                                  wsb.data_ptr(), wsb.numel() * 4, dx.data_ptr(), dx.stride(1), _p(dgamma), _p(dbeta),
+                                                  N, P, C, groups, int(silu), int(accumulate), _stream()), "vt_groupnorm_silu_bwd_cl")
+
+
+def geglu_fwd(h, y):
+    _req(h, BF16, "h", 2); _req(y, BF16, "y", 2)
+    check(load_library().vt_geglu_fwd(h.data_ptr(), h.stride(0), y.data_ptr(), y.stride(0), h.shape[0], y.shape[1], _stream()), "vt_geglu_fwd")
+
+
+def geglu_bwd(dy, h, dh):
+    _req(h, BF16, "h", 2); _req(dy, BF16, "dy", 2); _req(dh, BF16, "dh", 2)
+    check(load_library().vt_geglu_bwd(dy.data_ptr(), dy.stride(0), h.data_ptr(), h.stride(0), dh.data_ptr(), dh.stride(0), h.shape[0],
+                                      dy.shape[1], _stream()), "vt_geglu_bwd")
+
+
+def add_rows(a, b, out):
+    """out = a + b on 2-d bf16 row views (out may be a or b)"""
+    _req(a, BF16, "a", 2); _req(b, BF16, "b", 2); _req(out, BF16, "out", 2)
+    check(load_library().vt_add_rows_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0],
+                                          a.shape[1], _stream()), "vt_add_rows_bf16")
+
+
+def row_map(src, out, mode: int, nb: int, d1: int, d2: int, accumulate: bool = False):
+    """2-d bf16 row views; mode 0: [nb,d1,d2] -> [nb,d2,d1]; 1: nearest x2; 2: zero insertion; 3: 2x2 block sum (see vt355.h)"""
+    _req(src, BF16, "src", 2); _req(out, BF16, "out", 2)
+    rows_src = nb * d1 * d2 * (4 if mode == 3 else 1)
+    rows_out = nb * d1 * d2 * (4 if mode in (1, 2) else 1)
+    if src.shape[0] != rows_src or out.shape[0] != rows_out or src.shape[1] != out.shape[1]:
+        raise ValueError(f"row_map mode {mode}: src {tuple(src.shape)} out {tuple(out.shape)} do not match nb={nb} d1={d1} d2={d2}")
+    check(load_library().vt_row_map_bf16(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), mode, nb, d1, d2, src.shape[1],
+                                         int(accumulate), _stream()), "vt_row_map_bf16")
+
+
+def q_sample(x0, noise, sa, sb, scale, xt):
+    _req(x0, torch.float32, "x0"); _req(noise, torch.float32, "noise"); _req(xt, BF16, "xt")
+    B = x0.shape[0]
+    check(load_library().vt_q_sample(x0.data_ptr(), noise.data_ptr(), sa.data_ptr(), sb.data_ptr(), _p(scale), xt.data_ptr(),
+                                     x0.numel() // B, B, _stream()), "vt_q_sample")
+
+
+def mse_loss(pred, target, loss, dpred=None, grad_scale: float = 1.0):
+    _req(pred, BF16, "pred"); _req(target, torch.float32, "target"); _req(loss, torch.float32, "loss")
+    check(load_library().vt_mse_loss(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _p(dpred), pred.numel(), grad_scale, _stream()),
+          "vt_mse_loss")
+
+
+def attn_small_fwd(q, k, v, o, lse2, H: int, scale: float, mask_block: int = 0):
+    """q, o: [NB, Sq, >=H*64]; k, v: [NB, Sk, >=H*64] views (mask_block > 0: NB == 1, one packed row space)"""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _req(t, BF16, n, 3)
+    NB, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    check(load_library().vt_attn_small_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse2), NB, H, Sq, Sk,
+                                           q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                           o.stride(1), o.stride(0), scale, mask_block, _stream()), "vt_attn_small_fwd")
+
+
+def attn_small_bwd(q, k, v, o, do, lse2, dq, dk, dv, H: int, scale: float, mask_block: int = 0):
+    """mask_block > 0: dk, dv bf16 like k, v.  mask_block == 0: dk, dv fp32 [NB, Sk, H*64] contiguous, zeroed here, accumulated with atomics."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dq", dq)):
+        _req(t, BF16, n, 3)
+    NB, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    if mask_block > 0:
+        _req(dk, BF16, "dk", 3); _req(dv, BF16, "dv", 3)
+        args = (dk.data_ptr(), dv.data_ptr(), None, None)
+    else:
+        _req(dk, torch.float32, "dk", 3); _req(dv, torch.float32, "dv", 3)
+        if not (dk.is_contiguous() and dv.is_contiguous()):
+            raise ValueError("dk / dv accumulators must be contiguous")
+        dk.zero_(); dv.zero_()
+        args = (None, None, dk.data_ptr(), dv.data_ptr())
+    check(load_library().vt_attn_small_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse2.data_ptr(),
+                                           dq.data_ptr(), *args, NB, H, Sq, Sk,
+                                           q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                           o.stride(1), o.stride(0), do.stride(1), do.stride(0), dq.stride(1), dq.stride(0),
+                                           dk.stride(1), dv.stride(1), scale, mask_block, _stream()), "vt_attn_small_bwd")

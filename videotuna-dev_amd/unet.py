@@ -1,0 +1,845 @@
+"""VideoCrafter2 denoiser on the vt355 kernels: ``UNetModel`` with the constructor keys, parameter names and ``forward`` signature
+of videotuna/models/lvdm/modules/networks/openaimodel3d.py:313-694 (so ``configs/001_videocrafter2/*.yaml``'s ``denoiser_config`` /
+``unet_config`` node instantiates it through the target remap), and the forward / backward schedule of its blocks
+(ResBlock + TemporalConvBlock :123-310, Down/Upsample :56-120, SpatialTransformer / TemporalTransformer / CrossAttention / GEGLU
+lvdm/modules/attention.py:45-548) -- BASELINE configs[3], SURVEY 8(a) a11-a13.
+
+MI355X-first layout: ONE channels-last activation layout [B, T, H, W, C] (rows = positions, bf16) from the first convolution to the
+last.  The reference's ``(b t) c h w <-> b c t h w <-> (b h w) c t`` rearranges (openaimodel3d.py:45-47, 249-253; attention.py:476-516)
+do not exist: a Conv2d is the implicit-GEMM kernel with one temporal tap, the (3,1,1) convolution the same kernel with one spatial
+tap, GroupNorm over (b t) or over b is a choice of (N, P) on the same buffer, a Linear is a GEMM over the rows, spatial attention
+reads [B*T, H*W] sequences in place and the temporal transformer needs one row transpose each way.  Convolution weights live in
+channels-last memory format (logical torch shape, tap-major storage), so the kernels' operands are views of the flat parameter
+buffer and their weight gradients land in the flat fp32 gradient buffer without repacking.
+
+Training (full fine-tune, the configs' recipe): one autograd node for the whole network; the forward records a tape of closures,
+the backward replays it in reverse and accumulates parameter gradients (``+=``) into ``model.train_state.grad``.  Activations are
+kept (no per-block recompute: 288 GB of HBM; the reference checkpoints every block, ``use_checkpoint: true``).
+Deviation: TemporalConvBlock's dropout(0.1) (:285-296, active in the reference's train mode) is not applied.
+There is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BF16, EPI_BIAS, EPI_GATED_RES
+
+F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# module tree: layer descriptors in the order of UNetModel.__init__ (openaimodel3d.py:341-648)
+# ---------------------------------------------------------------------------------------------------------------------
+def build_structure(c) -> SimpleNamespace:
+    mc, hd = c.model_channels, c.num_head_channels
+    L = lambda kind, pre, **kw: SimpleNamespace(kind=kind, pre=pre, **kw)
+    inp = [[L("conv_in", "input_blocks.0.0", cin=c.in_channels, cout=mc)]]
+    chans = [mc]
+    ch, ds, idx = mc, 1, 1
+    for level, mult in enumerate(c.channel_mult):
+        for _ in range(c.num_res_blocks):
+            layers = [L("res", f"input_blocks.{idx}.0", cin=ch, cout=mult * mc, tconv=c.temporal_conv)]
+            ch = mult * mc
+            if ds in c.attention_resolutions:
+                layers.append(L("st", f"input_blocks.{idx}.1", c=ch, heads=ch // hd, inner=ch))
+                if c.temporal_attention:
+                    layers.append(L("tt", f"input_blocks.{idx}.2", c=ch, heads=ch // hd, inner=ch))
+            inp.append(layers); chans.append(ch); idx += 1
+        if level != len(c.channel_mult) - 1:
+            inp.append([L("down", f"input_blocks.{idx}.0", c=ch)]); chans.append(ch); idx += 1
+            ds *= 2
+    init_attn = L("tt", "init_attn.0", c=mc, heads=8, inner=8 * hd, conv1d=True) if c.addition_attention else None
+    mid = [L("res", "middle_block.0", cin=ch, cout=ch, tconv=c.temporal_conv), L("st", "middle_block.1", c=ch, heads=ch // hd, inner=ch)]
+    if c.temporal_attention:
+        mid.append(L("tt", "middle_block.2", c=ch, heads=ch // hd, inner=ch))
+    mid.append(L("res", f"middle_block.{len(mid)}", cin=ch, cout=ch, tconv=c.temporal_conv))
+    out, idx = [], 0
+    for level, mult in list(enumerate(c.channel_mult))[::-1]:
+        for i in range(c.num_res_blocks + 1):
+            ich = chans.pop()
+            layers = [L("res", f"output_blocks.{idx}.0", cin=ch + ich, cout=mult * mc, tconv=c.temporal_conv)]
+            ch = mult * mc
+            if ds in c.attention_resolutions:
+                layers.append(L("st", f"output_blocks.{idx}.{len(layers)}", c=ch, heads=ch // hd, inner=ch))
+                if c.temporal_attention:
+                    layers.append(L("tt", f"output_blocks.{idx}.{len(layers)}", c=ch, heads=ch // hd, inner=ch))
+            if level and i == c.num_res_blocks:
+                layers.append(L("up", f"output_blocks.{idx}.{len(layers)}", c=ch))
+                ds //= 2
+            out.append(layers); idx += 1
+    return SimpleNamespace(input=inp, init_attn=init_attn, middle=mid, output=out, out_ch=ch)
+
+
+def _param_shapes(c, st) -> Dict[str, tuple]:
+    """reference state_dict keys in registration order"""
+    mc, te = c.model_channels, 4 * c.model_channels
+    sh: Dict[str, tuple] = {}
+    for n in ["time_embed"] + (["fps_embedding"] if c.fps_cond else []):
+        sh[n + ".0.weight"] = (te, mc); sh[n + ".0.bias"] = (te,)
+        sh[n + ".2.weight"] = (te, te); sh[n + ".2.bias"] = (te,)
+
+    def transformer(l, ctx_dim):
+        pre, cc, inner = l.pre, l.c, l.inner
+        k1 = (1,) if getattr(l, "conv1d", False) else ()
+        sh[pre + ".norm.weight"] = (cc,); sh[pre + ".norm.bias"] = (cc,)
+        sh[pre + ".proj_in.weight"] = (inner, cc) + k1; sh[pre + ".proj_in.bias"] = (inner,)
+        b = pre + ".transformer_blocks.0."
+
+        def attn(a, kd):
+            sh[b + a + ".to_q.weight"] = (inner, inner); sh[b + a + ".to_k.weight"] = (inner, kd); sh[b + a + ".to_v.weight"] = (inner, kd)
+            sh[b + a + ".to_out.0.weight"] = (inner, inner); sh[b + a + ".to_out.0.bias"] = (inner,)
+        attn("attn1", inner)
+        sh[b + "ff.net.0.proj.weight"] = (8 * inner, inner); sh[b + "ff.net.0.proj.bias"] = (8 * inner,)
+        sh[b + "ff.net.2.weight"] = (inner, 4 * inner); sh[b + "ff.net.2.bias"] = (inner,)
+        attn("attn2", inner if ctx_dim is None else ctx_dim)
+        for n in ("norm1", "norm2", "norm3"):
+            sh[b + n + ".weight"] = (inner,); sh[b + n + ".bias"] = (inner,)
+        sh[pre + ".proj_out.weight"] = (cc, inner) + k1; sh[pre + ".proj_out.bias"] = (cc,)
+
+    def add(l):
+        pre = l.pre
+        if l.kind == "conv_in":
+            sh[pre + ".weight"] = (l.cout, l.cin, 3, 3); sh[pre + ".bias"] = (l.cout,)
+        elif l.kind == "res":
+            ci, co = l.cin, l.cout
+            sh[pre + ".in_layers.0.weight"] = (ci,); sh[pre + ".in_layers.0.bias"] = (ci,)
+            sh[pre + ".in_layers.2.weight"] = (co, ci, 3, 3); sh[pre + ".in_layers.2.bias"] = (co,)
+            sh[pre + ".emb_layers.1.weight"] = (co, te); sh[pre + ".emb_layers.1.bias"] = (co,)
+            sh[pre + ".out_layers.0.weight"] = (co,); sh[pre + ".out_layers.0.bias"] = (co,)
+            sh[pre + ".out_layers.3.weight"] = (co, co, 3, 3); sh[pre + ".out_layers.3.bias"] = (co,)
+            if ci != co:
+                sh[pre + ".skip_connection.weight"] = (co, ci, 1, 1); sh[pre + ".skip_connection.bias"] = (co,)
+            if l.tconv:
+                for j in (1, 2, 3, 4):
+                    last = 2 if j == 1 else 3
+                    sh[pre + f".temopral_conv.conv{j}.0.weight"] = (co,); sh[pre + f".temopral_conv.conv{j}.0.bias"] = (co,)
+                    sh[pre + f".temopral_conv.conv{j}.{last}.weight"] = (co, co, 3, 1, 1)
+                    sh[pre + f".temopral_conv.conv{j}.{last}.bias"] = (co,)
+        elif l.kind == "st":
+            transformer(l, c.context_dim)
+        elif l.kind == "tt":
+            transformer(l, None)
+        elif l.kind == "down":
+            sh[pre + ".op.weight"] = (l.c, l.c, 3, 3); sh[pre + ".op.bias"] = (l.c,)
+        elif l.kind == "up":
+            sh[pre + ".conv.weight"] = (l.c, l.c, 3, 3); sh[pre + ".conv.bias"] = (l.c,)
+
+    for blk in st.input:
+        for l in blk:
+            add(l)
+    if st.init_attn is not None:
+        add(st.init_attn)
+    for l in st.middle:
+        add(l)
+    for blk in st.output:
+        for l in blk:
+            add(l)
+    sh["out.0.weight"] = (st.out_ch,); sh["out.0.bias"] = (st.out_ch,)
+    sh["out.2.weight"] = (c.out_channels, mc, 3, 3); sh["out.2.bias"] = (c.out_channels,)
+    return sh
+
+
+class _Node(nn.Module):
+    pass
+
+
+def _is_conv(shape) -> bool:
+    return len(shape) in (4, 5)
+
+
+class UNetModel(nn.Module):
+    """Constructor keys of the reference's UNetModel (openaimodel3d.py:341-372); options the VideoCrafter2 recipes leave off are
+    refused instead of ignored."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None, use_scale_shift_norm=False,
+                 resblock_updown=False, num_heads=-1, num_head_channels=-1, transformer_depth=1, use_linear=False, use_checkpoint=False,
+                 temporal_conv=False, tempspatial_aware=False, temporal_attention=True, temporal_selfatt_only=True,
+                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
+                 addition_attention=False, use_image_attention=False, temporal_transformer_depth=1, fps_cond=False,
+                 text_context_len: int = 77):
+        super().__init__()
+        unsupported = dict(use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, tempspatial_aware=tempspatial_aware,
+                           use_relative_position=use_relative_position, use_causal_attention=use_causal_attention,
+                           use_image_attention=use_image_attention, not_use_linear=not use_linear, not_conv_resample=not conv_resample,
+                           not_selfatt_only=not temporal_selfatt_only, dropout=dropout != 0.0, depth=transformer_depth != 1 or temporal_transformer_depth != 1,
+                           dims=dims != 2, num_heads=num_heads != -1)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"vt355 UNetModel implements the VideoCrafter2 recipe (configs/001_videocrafter2); unsupported options: {bad}")
+        if num_head_channels != 64:
+            raise NotImplementedError("the attention kernels are built for num_head_channels = 64")
+        if model_channels % 64 or context_dim is None or context_dim % 64:
+            raise ValueError("model_channels and context_dim must be multiples of 64 (one K-tile of the GEMM / convolution kernels)")
+        if temporal_attention and (temporal_length is None or 32 % temporal_length):
+            raise ValueError("temporal_length must divide 32 (packed temporal attention, csrc/attn_small.hip)")
+        self.config = SimpleNamespace(in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
+                                      num_res_blocks=num_res_blocks, attention_resolutions=tuple(attention_resolutions),
+                                      channel_mult=tuple(channel_mult), context_dim=context_dim, num_head_channels=num_head_channels,
+                                      temporal_conv=temporal_conv, temporal_attention=temporal_attention, temporal_length=temporal_length,
+                                      addition_attention=addition_attention, fps_cond=fps_cond, use_checkpoint=use_checkpoint,
+                                      text_context_len=text_context_len)
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.structure = build_structure(self.config)
+        self.shapes = _param_shapes(self.config, self.structure)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for n, shp in self.shapes.items():
+            self.offsets[n] = off
+            off += (math.prod(shp) + 7) // 8 * 8            # every parameter starts on a 16-byte boundary of the flat buffer
+        self.numel = off
+        self.flat_bf16 = torch.zeros(off, dtype=BF16)
+        self._plist: Dict[str, nn.Parameter] = {}
+        for n, shp in self.shapes.items():
+            p = nn.Parameter(self._view(self.flat_bf16, n), requires_grad=True)
+            self._plist[n] = p
+            node = self
+            parts = n.split(".")
+            for a in parts[:-1]:
+                if not hasattr(node, a):
+                    node.add_module(a, _Node())
+                node = getattr(node, a)
+            node.register_parameter(parts[-1], p)
+        self.train_state = None
+        self._packed = None
+        self._packed_version = -1
+
+    # ---- flat storage ----
+    def _view(self, buf, name):
+        shp = self.shapes[name]
+        o = self.offsets[name]
+        v = buf[o:o + math.prod(shp)]
+        if len(shp) == 4:       # conv weight [Cout, Cin, KH, KW]: channels-last storage = the kernels' tap-major operand
+            return v.view(shp[0], shp[2], shp[3], shp[1]).permute(0, 3, 1, 2)
+        if len(shp) == 5:
+            return v.view(shp[0], shp[2], shp[3], shp[4], shp[1]).permute(0, 4, 1, 2, 3)
+        return v.view(shp)
+
+    def flat(self, buf, name, rows=None):
+        """2-d operand view of a parameter in a flat buffer: Linear [N, K]; conv [Cout, taps*Cin]; vector [n]"""
+        shp = self.shapes[name]
+        o = self.offsets[name]
+        v = buf[o:o + math.prod(shp)]
+        return v.view(shp[0], -1) if len(shp) > 1 else v
+
+    def span(self, buf, first, last):
+        """rows of `first` .. `last` (adjacent [*, K] matrices in the flat layout, e.g. to_q | to_k | to_v) as ONE [sum N, K] matrix"""
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + math.prod(self.shapes[last])
+        K = self.shapes[first][1]
+        return buf[o0:o1].view(-1, K)
+
+    def _apply(self, fn, *a, **k):
+        if self.train_state is not None:
+            raise RuntimeError("move / convert the model BEFORE enable_training(): optimizer state lives next to the parameters")
+        out = super()._apply(fn, *a, **k)
+        p0 = next(iter(self._plist.values()))
+        new = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        for n, p in self._plist.items():
+            self._view(new, n).copy_(p.detach())
+            p.data = self._view(new, n)
+        self.flat_bf16 = new
+        self._packed = None
+        return out
+
+    def load_state_dict(self, sd, strict: bool = True, **kw):
+        out = super().load_state_dict({k: v.to(BF16) for k, v in sd.items()}, strict=strict, **kw)
+        if self.train_state is not None:
+            self.train_state.flat.copy_(self.flat_bf16)
+            self.train_state.version += 1
+        self._packed = None
+        return out
+
+    def init_weights(self, seed: int = 0):
+        """seeded random init for synthetic runs (no checkpoints offline); nothing is left at the reference's zero init"""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for n, p in self._plist.items():
+                shp = self.shapes[n]
+                if len(shp) == 1:
+                    w = torch.randn(shp, generator=g) * 0.1 + (1.0 if n.endswith("weight") else 0.0)
+                else:
+                    w = torch.randn(shp, generator=g) * (0.7 / math.sqrt(math.prod(shp[1:])))
+                p.copy_(w.to(p.device, BF16))
+        self._packed = None
+        return self
+
+    def enable_training(self):
+        """full fine-tuning state: fp32 master copy and fp32 gradient buffer next to the flat bf16 parameters; hand
+        ``model.train_state`` to FusedAdamW(fullft_state=...)"""
+        if self.flat_bf16.dtype != BF16:
+            raise TypeError("the MI355X engine computes in bf16: call .bfloat16() first")
+        if self.train_state is None:
+            ts = SimpleNamespace(flat=self.flat_bf16.to(F32), grad=torch.zeros(self.numel, dtype=F32, device=self.flat_bf16.device),
+                                 flat_bf16=self.flat_bf16, params=list(self._plist.values()), version=0, numel=self.numel,
+                                 on_grads_ready=None)
+            ts.g = lambda name: self.flat(ts.grad, name)
+            self.train_state = ts
+        return self.train_state
+
+    @property
+    def dtype(self):
+        return self.flat_bf16.dtype
+
+    @property
+    def device(self):
+        return self.flat_bf16.device
+
+    # ---- forward ----
+    def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, **kwargs):
+        """x [B, C, T, H, W] bf16, timesteps int64 [B], context [B, L, context_dim], fps int | int64 [B] -> [B, C_out, T, H, W]
+        (openaimodel3d.py:650-694)"""
+        if features_adapter is not None:
+            raise NotImplementedError("features_adapter is not part of the VideoCrafter2 training path")
+        if not x.is_cuda:
+            raise RuntimeError("vt355 UNetModel runs only on an MI355X device (no CPU fallback)")
+        if x.dtype != BF16:
+            raise TypeError(f"x must be bf16 (model dtype), got {x.dtype}")
+        if context is None:
+            raise ValueError("context (text embeddings [B, L, context_dim]) is required")
+        B = x.shape[0]
+        if isinstance(fps, int):
+            fps = torch.full((B,), fps, dtype=torch.int64, device=x.device)
+        need_grad = torch.is_grad_enabled() and self.train_state is not None
+        if need_grad:
+            anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            return _UNetFn.apply(anchor, self, x, timesteps, context, fps)
+        out, _ = _Run(self, save=False).forward(x, timesteps, context, fps)
+        return out
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x, t, context, fps):
+        run = _Run(model, save=True)
+        out, _ = run.forward(x, t, context, fps)
+        ctx.run = run
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.run.backward(dout)
+        ctx.run = None
+        return None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operand packing: what the kernels read besides the flat views (transposed / flipped copies for the input gradients)
+# ---------------------------------------------------------------------------------------------------------------------
+def _packed(model: UNetModel) -> SimpleNamespace:
+    ver = -1 if model.train_state is None else model.train_state.version
+    if model._packed is not None and model._packed_version == ver:
+        return model._packed
+    P = SimpleNamespace(wt={}, wdx={}, w={})
+    fb = model.flat_bf16
+    train = model.train_state is not None
+    with torch.no_grad():
+        for n, shp in model.shapes.items():
+            if not n.endswith("weight") or len(shp) == 1:
+                continue
+            if _is_conv(shp) and not (len(shp) == 4 and shp[2] == 1):            # 3x3 / (3,1,1) convolutions
+                if train and n != "input_blocks.0.0.weight":
+                    w = model._plist[n].detach()
+                    if w.shape[0] % 64:         # out conv (4 output channels): its input-gradient conv reads dY padded to one K-tile
+                        wp_ = torch.zeros((w.shape[0] + 63) // 64 * 64, *w.shape[1:], dtype=BF16, device=w.device)
+                        wp_[:w.shape[0]] = w
+                        w = wp_
+                    P.wdx[n] = ops.pack_conv_weight_dx(w)
+            elif train:                                                          # Linear / 1x1 conv / Conv1d(k=1): [N, K]
+                P.wt[n] = model.flat(fb, n).t().contiguous()
+        # conv_in: 4 input channels padded to one 64-channel K-tile
+        w = model._plist["input_blocks.0.0.weight"].detach()                      # [mc, cin, 3, 3]
+        wp = torch.zeros(w.shape[0], 3, 3, 64, dtype=BF16, device=w.device)
+        wp[..., :w.shape[1]] = w.permute(0, 2, 3, 1)
+        P.w["conv_in"] = wp.view(w.shape[0], -1)
+    model._packed, model._packed_version = P, ver
+    return P
+
+
+class _Var:
+    """an activation [rows, C] (bf16, row stride may exceed C) and, during the backward pass, its gradient"""
+    __slots__ = ("d", "g")
+
+    def __init__(self, d):
+        self.d, self.g = d, None
+
+
+class _Run:
+    def __init__(self, model: UNetModel, save: bool):
+        self.m, self.save = model, save
+        self.c = model.config
+        self.P = _packed(model)
+        self.fb = model.flat_bf16
+        self.ts = model.train_state
+        self.tape: List = []
+        self.dev = model.device
+
+    # ---- small helpers ----
+    def E(self, *s, dt=BF16):
+        return torch.empty(*s, dtype=dt, device=self.dev)
+
+    def W(self, name):
+        return self.m.flat(self.fb, name)
+
+    def G(self, name):
+        return self.m.flat(self.ts.grad, name)
+
+    def acc(self, v: _Var, g):
+        if v.g is None:
+            v.g = g
+        else:
+            ops.add_rows(v.g, g, v.g)
+
+    def dW(self, dy, x, name_or_tensor):
+        dw = self.G(name_or_tensor) if isinstance(name_or_tensor, str) else name_or_tensor
+        P_, Q_ = dw.shape
+        if P_ % 128 == 0 and Q_ % 128 == 0 and dy.shape[0] >= 256:
+            ops.gemm_nt(dy, x, dw, P=P_, Q=Q_)
+        else:
+            ops.linear_dw(dy, x, dw, accumulate=True)
+
+    # ---- layers: each returns the output _Var and (when saving) pushes its backward onto the tape ----
+    def linear(self, x: _Var, wname: str, bname: Optional[str], residual: Optional[_Var] = None, wspan=None, out=None) -> _Var:
+        """y = x W^T + b (+ residual).  wspan = (first, last): several adjacent matrices as one (fused q|k|v)"""
+        w = self.m.span(self.fb, *wspan) if wspan else self.W(wname)
+        if w.dim() == 3:
+            w = w.view(w.shape[0], -1)
+        M = x.d.shape[0]
+        y = out if out is not None else self.E(M, w.shape[0])
+        b = None if bname is None else self.W(bname)
+        if residual is not None:
+            ops.gemm(x.d, w, y, b, epilogue=EPI_GATED_RES, residual=residual.d)
+        else:
+            ops.gemm(x.d, w, y, b)
+        yv = _Var(y)
+        if self.save:
+            def bwd():
+                g = yv.g
+                if residual is not None:
+                    self.acc(residual, g)
+                if bname is not None:
+                    ops.group_colsum(g, self.G(bname), D=w.shape[0])
+                if wspan:
+                    o0 = self.m.offsets[wspan[0]]
+                    dw = self.ts.grad[o0:o0 + w.numel()].view(w.shape)
+                    wt = self._wt_span(wspan)
+                else:
+                    dw = self.G(wname)
+                    if dw.dim() == 3:
+                        dw = dw.view(dw.shape[0], -1)
+                    wt = self.P.wt[wname]
+                self.dW(g, x.d, dw)
+                if x is not None and x.g is not False:
+                    dx = self.E(M, w.shape[1])
+                    ops.gemm(g, wt, dx, None)
+                    self.acc(x, dx)
+            self.tape.append(bwd)
+        return yv
+
+    def _wt_span(self, wspan):
+        key = "span:" + wspan[0]
+        if key not in self.P.wt:
+            self.P.wt[key] = self.m.span(self.fb, *wspan).t().contiguous()
+        return self.P.wt[key]
+
+    def groupnorm(self, x: _Var, pre: str, N: int, eps: float, silu: bool) -> _Var:
+        """x [N*P, C] as N samples of P positions"""
+        M, C = x.d.shape
+        P_ = M // N
+        y = self.E(M, C)
+        x3 = x.d.view(N, P_, C) if x.d.is_contiguous() else x.d.as_strided((N, P_, C), (P_ * x.d.stride(0), x.d.stride(0), 1))
+        ws = ops.groupnorm_fwd(x3, self.W(pre + ".weight"), self.W(pre + ".bias"), y.view(N, P_, C), 32, eps, silu)
+        yv = _Var(y)
+        if self.save:
+            def bwd():
+                g = yv.g
+                g3 = g.view(N, P_, C) if g.is_contiguous() else g.as_strided((N, P_, C), (P_ * g.stride(0), g.stride(0), 1))
+                if x.g is None:
+                    dx = self.E(M, C)
+                    ops.groupnorm_bwd(g3, x3, self.W(pre + ".weight"), ws, dx.view(N, P_, C), self.G(pre + ".weight"), self.G(pre + ".bias"), 32, silu)
+                    x.g = dx
+                else:
+                    xg = x.g
+                    xg3 = xg.view(N, P_, C) if xg.is_contiguous() else xg.as_strided((N, P_, C), (P_ * xg.stride(0), xg.stride(0), 1))
+                    ops.groupnorm_bwd(g3, x3, self.W(pre + ".weight"), ws, xg3, self.G(pre + ".weight"), self.G(pre + ".bias"), 32, silu,
+                                      accumulate=True)
+            self.tape.append(bwd)
+        return yv
+
+    def layernorm(self, x: _Var, pre: str) -> _Var:
+        M, D = x.d.shape
+        y = self.E(M, D)
+        mean, rstd = self.E(M, dt=F32), self.E(M, dt=F32)
+        ga, be = self.W(pre + ".weight"), self.W(pre + ".bias")
+        ops.ln_modulate_fwd(x.d, y, ga, be, None, mean, rstd, D, 1, 0, 1e-5)
+        yv = _Var(y)
+        if self.save:
+            def bwd():
+                g = yv.g
+                G1 = torch.zeros(1, D, dtype=F32, device=self.dev); G2 = torch.zeros(1, D, dtype=F32, device=self.dev)
+                ops.group_colsum(g, G1, y=x.d, out2=G2, mean=mean, rstd=rstd, D=D)
+                ops.ln_param_combine(G1, G2, D, ga, be, None, self.G(pre + ".weight"), self.G(pre + ".bias"), None, False)
+                dx = self.E(M, D)
+                ops.ln_modulate_bwd(g, x.d, mean, rstd, ga, None, x.g, dx, D, 1, 0)     # dx = (earlier gradient of x) + LN'(g)
+                x.g = dx
+            self.tape.append(bwd)
+        return yv
+
+    def self_attention_spatial(self, x: _Var, pre: str, heads: int, nseq: int, residual: _Var) -> _Var:
+        """CrossAttention with context None over nseq sequences of M/nseq rows (attention.py:101-181) + residual"""
+        M, C = x.d.shape
+        S = M // nseq
+        qkv = self.linear(x, None, None, wspan=(pre + ".to_q.weight", pre + ".to_v.weight"))
+        o = self.E(M, C)
+        lse = self.E(nseq, heads, S, dt=F32)
+        q3 = qkv.d.view(nseq, S, 3 * C)
+        ops.attn_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(nseq, S, C), lse, nseq, heads, S, scale=0.125)
+        ov = _Var(o)
+        if self.save:
+            def bwd():
+                g = ov.g
+                dqkv = self.E(M, 3 * C)
+                dq = torch.zeros(nseq, S, C, dtype=F32, device=self.dev)
+                delta = self.E(nseq * heads * S, dt=F32)
+                d3 = dqkv.view(nseq, S, 3 * C)
+                ops.attn_bwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(nseq, S, C), g.view(nseq, S, C), lse, delta, dq,
+                             d3[:, :, C:2 * C], d3[:, :, 2 * C:], nseq, heads, S, scale=0.125,
+                             chain_ws=ops.attn_bwd_chain_workspace(nseq, heads, S, self.dev))
+                ops.residual_cast(dq.view(M, C), None, dqkv[:, :C])
+                qkv.g = dqkv
+            self.tape.append(bwd)
+        return self.linear(ov, pre + ".to_out.0.weight", pre + ".to_out.0.bias", residual=residual)
+
+    def attention_packed(self, x: _Var, pre: str, heads: int, T: int, residual: _Var) -> _Var:
+        """temporal self-attention: rows are consecutive sequences of T (attention.py:395-519; both attn1 and attn2)"""
+        M, C = x.d.shape
+        qkv = self.linear(x, None, None, wspan=(pre + ".to_q.weight", pre + ".to_v.weight"))
+        o = self.E(M, C)
+        lse = self.E(1, heads, M, dt=F32)
+        q3 = qkv.d.view(1, M, 3 * C)
+        ops.attn_small_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(1, M, C), lse, heads, 0.125, mask_block=T)
+        ov = _Var(o)
+        if self.save:
+            def bwd():
+                dqkv = self.E(M, 3 * C)
+                d3 = dqkv.view(1, M, 3 * C)
+                ops.attn_small_bwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(1, M, C), ov.g.view(1, M, C), lse,
+                                   d3[:, :, :C], d3[:, :, C:2 * C], d3[:, :, 2 * C:], heads, 0.125, mask_block=T)
+                qkv.g = dqkv
+            self.tape.append(bwd)
+        return self.linear(ov, pre + ".to_out.0.weight", pre + ".to_out.0.bias", residual=residual)
+
+    def cross_attention(self, x: _Var, pre: str, heads: int, B: int, ctx: _Var, L: int, residual: _Var) -> _Var:
+        """text cross-attention: the M/B rows of a sample against its L context rows (attention.py:101-181, context[:, :77])"""
+        M, C = x.d.shape
+        q = self.linear(x, pre + ".to_q.weight", None)
+        kv = self.linear(ctx, None, None, wspan=(pre + ".to_k.weight", pre + ".to_v.weight"))        # [B*L, 2C]
+        o = self.E(M, C)
+        lse = self.E(B, heads, M // B, dt=F32)
+        kv3 = kv.d.view(B, L, 2 * C)
+        ops.attn_small_fwd(q.d.view(B, M // B, C), kv3[:, :, :C], kv3[:, :, C:], o.view(B, M // B, C), lse, heads, 0.125)
+        ov = _Var(o)
+        if self.save:
+            def bwd():
+                dq = self.E(M, C)
+                dk = self.E(B, L, C, dt=F32); dv = self.E(B, L, C, dt=F32)
+                ops.attn_small_bwd(q.d.view(B, M // B, C), kv3[:, :, :C], kv3[:, :, C:], o.view(B, M // B, C), ov.g.view(B, M // B, C), lse,
+                                   dq.view(B, M // B, C), dk, dv, heads, 0.125)
+                q.g = dq
+                dkv = self.E(B * L, 2 * C)
+                ops.residual_cast(dk.view(B * L, C), None, dkv[:, :C])
+                ops.residual_cast(dv.view(B * L, C), None, dkv[:, C:])
+                kv.g = dkv
+            self.tape.append(bwd)
+        return self.linear(ov, pre + ".to_out.0.weight", pre + ".to_out.0.bias", residual=residual)
+
+    def feed_forward(self, x: _Var, pre: str, residual: _Var) -> _Var:
+        h = self.linear(x, pre + ".net.0.proj.weight", pre + ".net.0.proj.bias")
+        M, F2 = h.d.shape
+        y = self.E(M, F2 // 2)
+        ops.geglu_fwd(h.d, y)
+        yv = _Var(y)
+        if self.save:
+            def bwd():
+                dh = self.E(M, F2)
+                ops.geglu_bwd(yv.g, h.d, dh)
+                h.g = dh
+            self.tape.append(bwd)
+        return self.linear(yv, pre + ".net.2.weight", pre + ".net.2.bias", residual=residual)
+
+    def conv(self, x5, wname: str, bname: str, kernel, padding, stride=1, sbias=None, residual5=None, wk=None, cin=None):
+        """x5: bf16 [B,T,H,W,Cin] view; returns (y5, backward closure factory) -- the caller wraps the Vars"""
+        wk_ = wk if wk is not None else self.W(wname)
+        B, T, H, W_, _ = x5.shape
+        Ho, Wo = (H + 2 * padding[1] - kernel[1]) // stride + 1, (W_ + 2 * padding[2] - kernel[2]) // stride + 1
+        Cout = wk_.shape[0]
+        ld = Cout if Cout % 8 == 0 else (Cout + 7) // 8 * 8
+        y5 = self.E(B, T, Ho, Wo, ld)[..., :Cout]
+        ops.conv_cl(x5, wk_, y5, kernel, padding, stride, bias=self.W(bname), sbias=sbias, residual=residual5)
+        return y5
+
+    def conv_bwd(self, g5, x5, wname, bname, kernel, padding, stride, need_dx=True, cin_true=None):
+        """parameter gradients of a convolution and (returned) the gradient of its input"""
+        Cout = g5.shape[4]
+        g2 = g5.as_strided((g5.shape[0] * g5.shape[1] * g5.shape[2] * g5.shape[3], Cout), (g5.stride(3), 1))      # rows x channels view (row stride may exceed Cout)
+        ops.group_colsum(g2, self.G(bname), D=Cout)
+        dw = self.G(wname)
+        xs = x5 if cin_true is None else x5[..., :cin_true]
+        ops.conv_dw_cl(g5, xs, dw, kernel, padding, stride, accumulate=True)
+        if not need_dx:
+            return None
+        B, T, H, W_, Cin = x5.shape
+        dx5 = self.E(B, T, H, W_, Cin)
+        if Cout % 64:                     # pad dY's channels to a whole K-tile (weights were padded alike in _packed)
+            gp = torch.zeros(*g5.shape[:4], (Cout + 63) // 64 * 64, dtype=BF16, device=self.dev)
+            gp[..., :Cout] = g5
+            g5, Cout = gp, gp.shape[4]
+            g2 = g5.view(-1, Cout)
+        if stride == 1:
+            ops.conv_cl(g5, self.P.wdx[wname], dx5, kernel, padding, 1)
+        else:
+            z = self.E(B, T, H, W_, Cout)
+            ops.row_map(g2, z.view(-1, Cout), 2, B * T, g5.shape[2], g5.shape[3])
+            ops.conv_cl(z, self.P.wdx[wname], dx5, kernel, padding, 1)
+        return dx5
+
+    # ---- blocks ----
+    def res_block(self, l, x: _Var, shape, se: _Var, demb) -> _Var:
+        """ResBlock._forward + TemporalConvBlock (openaimodel3d.py:229-310).  x rows = [B,T,H,W]; se = SiLU(emb) [B, te]"""
+        B, T, H, W_ = shape
+        pre, ci, co = l.pre, l.cin, l.cout
+        M = B * T * H * W_
+        k2, p2, kt, pt = (1, 3, 3), (0, 1, 1), (3, 1, 1), (1, 0, 0)
+        x5 = x.d.view(B, T, H, W_, ci)
+        h0 = self.groupnorm(x, pre + ".in_layers.0", B * T, 1e-5, True)
+        eo = self.E(B, co, dt=F32)
+        ops.gemm(se.d, self.W(pre + ".emb_layers.1.weight"), eo, self.W(pre + ".emb_layers.1.bias"))       # emb_out, fp32 [B, co]
+        h1d = self.conv(h0.d.view(B, T, H, W_, ci), pre + ".in_layers.2.weight", pre + ".in_layers.2.bias", k2, p2, sbias=eo)
+        h1 = _Var(h1d.view(M, co))
+        if self.save:
+            def bwd1():
+                g5 = h1.g.view(B, T, H, W_, co)
+                # emb_out gradient: per-sample column sums of dh -> Linear(SiLU(emb)) backward (few rows: vt_small_linear_bwd)
+                deo = torch.zeros(B, co, dtype=F32, device=self.dev)
+                ops.group_colsum(h1.g, deo, D=co, S=T * H * W_, St=0, grouped=True, o_bstride=co, o_segstride=0)
+                ops.small_linear_bwd(deo, se.d, self.W(pre + ".emb_layers.1.weight"), self.G(pre + ".emb_layers.1.weight"),
+                                     self.G(pre + ".emb_layers.1.bias"), demb)
+                h0.g = self.conv_bwd(g5, h0.d.view(B, T, H, W_, ci), pre + ".in_layers.2.weight", pre + ".in_layers.2.bias", k2, p2, 1).view(M, ci)
+            self.tape.append(bwd1)
+        h2 = self.groupnorm(h1, pre + ".out_layers.0", B * T, 1e-5, True)
+        if ci != co:
+            skip = self.linear(x, pre + ".skip_connection.weight", pre + ".skip_connection.bias")
+        else:
+            skip = x
+        h3d = self.conv(h2.d.view(B, T, H, W_, co), pre + ".out_layers.3.weight", pre + ".out_layers.3.bias", k2, p2,
+                        residual5=skip.d.view(B, T, H, W_, co))
+        h3 = _Var(h3d.view(M, co))
+        if self.save:
+            def bwd2():
+                g5 = h3.g.view(B, T, H, W_, co)
+                self.acc(skip, h3.g)
+                h2.g = self.conv_bwd(g5, h2.d.view(B, T, H, W_, co), pre + ".out_layers.3.weight", pre + ".out_layers.3.bias", k2, p2, 1).view(M, co)
+            self.tape.append(bwd2)
+        if not l.tconv:
+            return h3
+        cur = h3
+        for j in (1, 2, 3, 4):
+            last = 2 if j == 1 else 3
+            pj = pre + f".temopral_conv.conv{j}"
+            gn = self.groupnorm(cur, pj + ".0", B, 1e-5, True)
+            yd = self.conv(gn.d.view(B, T, H, W_, co), pj + f".{last}.weight", pj + f".{last}.bias", kt, pt,
+                           residual5=h3.d.view(B, T, H, W_, co) if j == 4 else None)
+            nxt = _Var(yd.view(M, co))
+            if self.save:
+                def bwdt(nxt=nxt, gn=gn, pj=pj, last=last, j=j):
+                    g5 = nxt.g.view(B, T, H, W_, co)
+                    if j == 4:
+                        self.acc(h3, nxt.g)
+                    gn.g = self.conv_bwd(g5, gn.d.view(B, T, H, W_, co), pj + f".{last}.weight", pj + f".{last}.bias", kt, pt, 1).view(M, co)
+                self.tape.append(bwdt)
+            cur = nxt
+        return cur
+
+    def basic_block(self, x: _Var, pre: str, heads: int, mode: str, **kw) -> _Var:
+        """BasicTransformerBlock._forward (attention.py:299-310)"""
+        b = pre + ".transformer_blocks.0."
+        if mode == "spatial":
+            x = self.self_attention_spatial(self.layernorm(x, b + "norm1"), b + "attn1", heads, kw["nseq"], x)
+            x = self.cross_attention(self.layernorm(x, b + "norm2"), b + "attn2", heads, kw["B"], kw["ctx"], kw["L"], x)
+        else:
+            x = self.attention_packed(self.layernorm(x, b + "norm1"), b + "attn1", heads, kw["T"], x)
+            x = self.attention_packed(self.layernorm(x, b + "norm2"), b + "attn2", heads, kw["T"], x)
+        return self.feed_forward(self.layernorm(x, b + "norm3"), b + "ff", x)
+
+    def spatial_transformer(self, l, x: _Var, shape, ctx: _Var, L: int) -> _Var:
+        B, T, H, W_ = shape
+        n = self.groupnorm(x, l.pre + ".norm", B * T, 1e-6, False)
+        h = self.linear(n, l.pre + ".proj_in.weight", l.pre + ".proj_in.bias")
+        h = self.basic_block(h, l.pre, l.heads, "spatial", nseq=B * T, B=B, ctx=ctx, L=L)
+        return self.linear(h, l.pre + ".proj_out.weight", l.pre + ".proj_out.bias", residual=x)
+
+    def temporal_transformer(self, l, x: _Var, shape) -> _Var:
+        B, T, H, W_ = shape
+        M, C = x.d.shape
+        n = self.groupnorm(x, l.pre + ".norm", B, 1e-6, False)
+        nt = self.E(M, C)
+        ops.row_map(n.d, nt, 0, B, T, H * W_)                      # [B, T, HW] -> [B, HW, T] rows
+        ntv = _Var(nt)
+        if self.save:
+            def bwd_in():
+                g = self.E(M, C)
+                ops.row_map(ntv.g, g, 0, B, H * W_, T)
+                n.g = g
+            self.tape.append(bwd_in)
+        h = self.linear(ntv, l.pre + ".proj_in.weight", l.pre + ".proj_in.bias")
+        h = self.basic_block(h, l.pre, l.heads, "temporal", T=T)
+        o = self.linear(h, l.pre + ".proj_out.weight", l.pre + ".proj_out.bias")
+        y = self.E(M, C)
+        ops.row_map(o.d, y, 0, B, H * W_, T)                       # back to [B, T, HW] rows ...
+        ops.add_rows(y, x.d, y)                                    # ... + x_in
+        yv = _Var(y)
+        if self.save:
+            def bwd_out():
+                g = self.E(M, C)
+                ops.row_map(yv.g, g, 0, B, T, H * W_)
+                o.g = g
+                self.acc(x, yv.g)
+            self.tape.append(bwd_out)
+        return yv
+
+    # ---- whole network ----
+    def forward(self, x, timesteps, context, fps):
+        c, m = self.c, self.m
+        B, Cin, T, H, W_ = x.shape
+        mc, te = c.model_channels, 4 * c.model_channels
+        dev = self.dev
+        # time / fps embedding (openaimodel3d.py:651-660): sinusoid -> Linear -> SiLU -> Linear, summed
+        def embed(idx, name):
+            sin = self.E(B, mc); ops.timestep_embedding(idx.to(torch.int64).contiguous(), sin, True, 0.0)
+            l0 = self.E(B, te); ops.gemm(sin, self.W(name + ".0.weight"), l0, self.W(name + ".0.bias"))
+            a0 = self.E(B, te); ops.silu(l0, a0)
+            return sin, l0, a0
+        sin_t, l0_t, a0_t = embed(timesteps, "time_embed")
+        emb = self.E(B, te); ops.gemm(a0_t, self.W("time_embed.2.weight"), emb, self.W("time_embed.2.bias"))
+        if c.fps_cond:
+            sin_f, l0_f, a0_f = embed(fps, "fps_embedding")
+            emb2 = self.E(B, te)
+            ops.gemm(a0_f, self.W("fps_embedding.2.weight"), emb2, self.W("fps_embedding.2.bias"), epilogue=EPI_GATED_RES, residual=emb)
+            emb = emb2
+        se = self.E(B, te); ops.silu(emb, se)
+        sev = _Var(se)
+        demb = torch.zeros(B, te, dtype=F32, device=dev) if self.save else None            # d loss / d SiLU(emb), summed over the ResBlocks
+        if self.save:
+            def bwd_emb():
+                d_emb = torch.zeros(B, te, dtype=F32, device=dev)
+                ops.silu_bwd(demb, emb, d_emb)
+                for (sin, l0, a0, name) in ([(sin_t, l0_t, a0_t, "time_embed")] + ([(sin_f, l0_f, a0_f, "fps_embedding")] if c.fps_cond else [])):
+                    da0 = torch.zeros(B, te, dtype=F32, device=dev)
+                    ops.small_linear_bwd(d_emb, a0, self.W(name + ".2.weight"), self.G(name + ".2.weight"), self.G(name + ".2.bias"), da0)
+                    dl0 = torch.zeros(B, te, dtype=F32, device=dev)
+                    ops.silu_bwd(da0, l0, dl0)
+                    ops.small_linear_bwd(dl0, sin, self.W(name + ".0.weight"), self.G(name + ".0.weight"), self.G(name + ".0.bias"), None)
+            self.tape.append(bwd_emb)
+        # context: the first text_context_len rows of every sample (attention.py:117-118), one [B*L, ctx] operand for all layers
+        L = min(context.shape[1], c.text_context_len)
+        ctx2 = context[:, :L].to(BF16).contiguous().view(B * L, -1)
+        ctxv = _Var(ctx2); ctxv.g = False          # frozen text encoder: no gradient wanted
+        # input: [B,C,T,H,W] -> channels-last rows, 4 channels padded to one 64-wide K-tile
+        x64 = torch.zeros(B, T, H, W_, 64, dtype=BF16, device=dev)
+        x64[..., :Cin] = x.permute(0, 2, 3, 4, 1)
+        shape = [B, T, H, W_]
+        hs: List = []
+
+        def run_layers(layers, h: _Var) -> _Var:
+            nonlocal shape
+            for l in layers:
+                Bq, Tq, Hq, Wq = shape
+                if l.kind == "conv_in":
+                    y5 = self.conv(x64, l.pre + ".weight", l.pre + ".bias", (1, 3, 3), (0, 1, 1), wk=self.P.w["conv_in"])
+                    h = _Var(y5.view(-1, l.cout))
+                    if self.save:
+                        def bwd_in(h=h, l=l):
+                            self.conv_bwd(h.g.view(Bq, Tq, Hq, Wq, l.cout), x64, l.pre + ".weight", l.pre + ".bias", (1, 3, 3), (0, 1, 1), 1,
+                                          need_dx=False, cin_true=Cin)
+                        self.tape.append(bwd_in)
+                elif l.kind == "res":
+                    h = self.res_block(l, h, shape, sev, demb)
+                elif l.kind == "st":
+                    h = self.spatial_transformer(l, h, shape, ctxv, L)
+                elif l.kind == "tt":
+                    h = self.temporal_transformer(l, h, shape)
+                elif l.kind == "down":
+                    xin = h
+                    y5 = self.conv(xin.d.view(Bq, Tq, Hq, Wq, l.c), l.pre + ".op.weight", l.pre + ".op.bias", (1, 3, 3), (0, 1, 1), stride=2)
+                    h = _Var(y5.view(-1, l.c))
+                    shape = [Bq, Tq, y5.shape[2], y5.shape[3]]
+                    if self.save:
+                        def bwd_dn(h=h, xin=xin, l=l, so=(y5.shape[2], y5.shape[3])):
+                            dx5 = self.conv_bwd(h.g.view(Bq, Tq, so[0], so[1], l.c), xin.d.view(Bq, Tq, Hq, Wq, l.c), l.pre + ".op.weight",
+                                                l.pre + ".op.bias", (1, 3, 3), (0, 1, 1), 2)
+                            self.acc(xin, dx5.view(-1, l.c))
+                        self.tape.append(bwd_dn)
+                elif l.kind == "up":
+                    xin = h
+                    up = self.E(Bq * Tq * 4 * Hq * Wq, l.c)
+                    ops.row_map(xin.d, up, 1, Bq * Tq, Hq, Wq)
+                    y5 = self.conv(up.view(Bq, Tq, 2 * Hq, 2 * Wq, l.c), l.pre + ".conv.weight", l.pre + ".conv.bias", (1, 3, 3), (0, 1, 1))
+                    h = _Var(y5.view(-1, l.c))
+                    shape = [Bq, Tq, 2 * Hq, 2 * Wq]
+                    if self.save:
+                        def bwd_up(h=h, xin=xin, l=l, up=up):
+                            dup = self.conv_bwd(h.g.view(Bq, Tq, 2 * Hq, 2 * Wq, l.c), up.view(Bq, Tq, 2 * Hq, 2 * Wq, l.c), l.pre + ".conv.weight",
+                                                l.pre + ".conv.bias", (1, 3, 3), (0, 1, 1), 1)
+                            dx = self.E(Bq * Tq * Hq * Wq, l.c)
+                            ops.row_map(dup.view(-1, l.c), dx, 3, Bq * Tq, Hq, Wq)
+                            self.acc(xin, dx)
+                        self.tape.append(bwd_up)
+            return h
+
+        st = m.structure
+        h = None
+        for i, blk in enumerate(st.input):
+            h = run_layers(blk, h)
+            if i == 0 and st.init_attn is not None:
+                h = run_layers([st.init_attn], h)
+            hs.append(h)
+        h = run_layers(st.middle, h)
+        for blk in st.output:
+            skip = hs.pop()
+            c1, c2 = h.d.shape[1], skip.d.shape[1]
+            cat = self.E(h.d.shape[0], c1 + c2)
+            cat[:, :c1].copy_(h.d); cat[:, c1:].copy_(skip.d)            # torch.cat([h, hs.pop()], dim=1): a column concat here
+            cv = _Var(cat)
+            if self.save:
+                def bwd_cat(cv=cv, a=h, b=skip, c1=c1):
+                    self.acc(a, cv.g[:, :c1])
+                    self.acc(b, cv.g[:, c1:])
+                self.tape.append(bwd_cat)
+            h = run_layers(blk, cv)
+        Bq, Tq, Hq, Wq = shape
+        n = self.groupnorm(h, "out.0", Bq * Tq, 1e-5, True)
+        y5 = self.conv(n.d.view(Bq, Tq, Hq, Wq, -1), "out.2.weight", "out.2.bias", (1, 3, 3), (0, 1, 1))
+        Co = c.out_channels
+        if self.save:
+            def bwd_out():
+                g5 = self._dout5
+                n.g = self.conv_bwd(g5, n.d.view(Bq, Tq, Hq, Wq, -1), "out.2.weight", "out.2.bias", (1, 3, 3), (0, 1, 1), 1).view(-1, n.d.shape[1])
+            self.tape.append(bwd_out)
+        out = y5.permute(0, 4, 1, 2, 3).contiguous()                     # -> [B, C_out, T, H, W] (the reference's layout at the boundary)
+        return out, None
+
+    def backward(self, dout):
+        """dout [B, C_out, T, H, W] bf16"""
+        B, Co, T, H, W_ = dout.shape
+        g = torch.zeros(B, T, H, W_, (Co + 7) // 8 * 8, dtype=BF16, device=self.dev)
+        g[..., :Co] = dout.permute(0, 2, 3, 4, 1)
+        self._dout5 = g[..., :Co]
+        while self.tape:
+            self.tape.pop()()
+        self._dout5 = None

@@ -91,6 +91,108 @@ def cpu_baseline(seconds_budget=40.0):
             "block_seconds": dt, "host_cpus": os.cpu_count()}
 
 
+def bench_vc2(args):
+    """BASELINE configs[3]: VideoCrafter2 T2V 320x512 UNet (configs/001_videocrafter2/vc2_t2v_320x512.yaml: batch_size 4, 16 frames,
+    latents [4,4,16,40,64], context [4,77,1024], fps 24), full fine-tune: q_sample -> UNet -> eps-MSE -> backward -> fused AdamW.
+    One step = one optimizer step on one micro-batch of 4 samples (--accum 1 default here; the yaml's trainer accumulates 2)."""
+    from vt355 import ops
+    from vt355.ddp import FlatGradReducer, broadcast_flat, init_from_env
+    from vt355.lvdm import LVDMFlow
+    rank, local, world = init_from_env(os.environ.get("VT_DDP_BACKEND"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("VT_ONE_GPU") == "1":
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    unet = dict(target="vt355.unet.UNetModel", params=dict(
+        in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4],
+        num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True, use_checkpoint=True, temporal_conv=True,
+        temporal_attention=True, temporal_selfatt_only=True, use_relative_position=False, use_causal_attention=False,
+        temporal_length=16, addition_attention=True, fps_cond=True))
+    flow = LVDMFlow(denoiser_config=unet, scheduler_config=dict(target="vt355.lvdm.LDDPM", params=dict(timesteps=1000, linear_start=0.00085, linear_end=0.012)),
+                    use_scale=True, scale_b=0.7, base_learning_rate=6e-6)
+    flow.model.init_weights(1234)
+    flow.to(dev)
+    opt = flow.configure_optimizers()
+    ts = flow.model.train_state
+    broadcast_flat(ts.flat); broadcast_flat(ts.flat_bf16)
+    red = FlatGradReducer(ts.grad)
+    B = args.micro_batch if args.micro_batch != 2 else 4          # the recipe's batch_size (the CogVideoX default of this flag is 2)
+    accum = args.accum if args.accum != 2 else 1
+    dgen = torch.Generator(device=dev).manual_seed(20230211 + rank)
+
+    def make_batch():
+        z = torch.randn(B, 4, 16, 40, 64, device=dev, generator=dgen) * 0.18215 * 5.0
+        ctx = (torch.randn(B, 77, 1024, device=dev, generator=dgen)).to(torch.bfloat16)
+        noise = torch.randn(B, 4, 16, 40, 64, device=dev, generator=dgen)
+        t = torch.randint(0, 1000, (B,), device=dev, generator=dgen)
+        return z, ctx, noise, t
+
+    losses = []
+
+    def step():
+        opt.zero_grad()
+        for _ in range(accum):
+            z, ctx, noise, t = make_batch()
+            loss = flow.loss_from(z, ctx, t, noise, fps=24)
+            (loss / accum).backward()
+            losses.append(loss.detach())
+        red.reduce_async(); red.wait()
+        opt.step(grad_scale=red.grad_scale)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, work = ops.profile_collect(), ops.profile_work()
+    ops.profile_reset(False)
+    opt.check_errors()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    samples = world * B * accum * args.steps
+    if rank == 0:
+        lv = [float(x) for x in torch.stack(losses[-accum * args.steps:]).cpu()]
+        kern = {}
+        for name, (ms, n) in prof.items():
+            kern[name] = {"avg_ms": ms, "launches": n}
+            if name in work:
+                kern[name]["tflops_algorithmic"] = work[name] / (ms * n) / 1e9
+        fwd_tflop = 12.58            # SURVEY 8(d): measured with FlopCounterMode on the imported reference UNet, per sample
+        step_tflop = 3.0 * fwd_tflop * B * accum
+        ach = kern.get("conv", {}).get("tflops_algorithmic")
+        res = {"metric": "finetune samples/sec, VideoCrafter2 T2V 320x512 UNet full-FT bf16", "value": samples / elapsed, "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "VideoCrafter2 T2V 320x512 UNet (configs[3], NOT the headline config): latents [4,4,16,40,64], context "
+                                      "[4,77,1024], fps 24, all 1.41 B weights trained (fp32 master + fused AdamW), no activation recompute, "
+                                      "TemporalConvBlock dropout off",
+                          "micro_batch": B, "accumulate_grad_batches": accum, "global_batch": world * B * accum, "parallelism": f"dp{world}",
+                          "weights": "seeded random init (no checkpoints offline)", "latents": "pre-encoded latents (synthetic)",
+                          "text": "pre-encoded OpenCLIP embeddings (synthetic)"},
+               "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+               "step_tflops_algorithmic": step_tflop * args.steps / elapsed,
+               "roofline": {"bound": "mfma", "kernel": "convnd_cl_kernel", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": (ach / 2500.0) if ach else None, "traffic": None,
+                            "note": "all forward / input-gradient convolutions of the step, 2*M*Cout*taps*Cin FLOPs each, HIP events on the launch stream"},
+               "kernels": kern, "loss_first": lv[0], "loss_last": lv[-1]}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,9 +202,10 @@ def main():
     ap.add_argument("--accum", type=int, default=2)
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["2b", "5b"], default="2b",
+    ap.add_argument("--model", choices=["2b", "5b", "vc2"], default="2b",
                     help="2b = the benchmark (BASELINE configs[1]); 5b = CogVideoX-5B dimensions (48 heads, 42 layers, rotary q/k) -- "
-                         "extra data point, labelled as such, never the headline line")
+                         "extra data point, labelled as such, never the headline line; vc2 = BASELINE configs[3], the VideoCrafter2 "
+                         "320x512 UNet (full fine-tune of 1.41 B weights, latents [4,4,16,40,64]) -- its own metric line")
     ap.add_argument("--text-encoder", action="store_true",
                     help="extra data point: the frozen T5-XXL encoder (vt355.t5, random weights) produces every micro-batch's text "
                          "embeddings inside the loop, one step ahead on a side stream (SURVEY 8(f) row 1); default: pre-encoded text")
@@ -132,6 +235,9 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+
+    if args.model == "vc2":
+        return bench_vc2(args)
 
     from vt355 import ops
     from vt355.ddp import BucketedReducer, FlatGradReducer, broadcast_flat, init_from_env

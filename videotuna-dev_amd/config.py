@@ -18,6 +18,12 @@ TARGET_REMAP = {
     "videotuna.models.cogvideo_hf.cogvideo_i2v.CogVideoXI2V": "vt355.workflow.CogVideoXI2V",
     "videotuna.models.lvdm.modules.encoders.condition.FrozenT5Embedder": "vt355.t5.FrozenT5Embedder",
     "transformers.T5EncoderModel": "vt355.t5.T5EncoderModel",
+    # VideoCrafter2 (configs/001_videocrafter2/*.yaml)
+    "videotuna.models.lvdm.modules.networks.openaimodel3d.UNetModel": "vt355.unet.UNetModel",
+    "videotuna.flow.videocrafter.VideocrafterFlow": "vt355.lvdm.VideocrafterFlow",
+    "videotuna.models.lvdm.ddpm3d.LVDMFlow": "vt355.lvdm.LVDMFlow",
+    "videotuna.schedulers.ddpm.LDDPM": "vt355.lvdm.LDDPM",
+    "videotuna.schedulers.diffusion_schedulers.LDMScheduler": "vt355.lvdm.LDMScheduler",
 }
 _NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
 

@@ -195,7 +195,7 @@ extern "C" int vt_conv_cl(const void* x, long long ldx, const void* wk, const vo
     if (sbias != nullptr && ((sbias_ld % 4) || sbias_ld < Cout)) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)wk) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)sbias)) & 15) return VT_ERR_BAD_ALIGN;
     const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
-    const long long xb = rows_in * ldx * 2;
+    const long long xb = ((rows_in - 1) * ldx + Cin) * 2;       // ends with the last row's Cin columns (x may be a column slice of a wider buffer)
     if (xb >= 0x7fffffffLL || rows_out >= 0x7fffffffLL || (long long)KT * KH * KW * Cin * 2 * CN_BN >= 0x7fffffffLL) return VT_ERR_BAD_SHAPE;
     ConvNdParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wk; p.y = (bf16_t*)y; p.bias = (const bf16_t*)bias; p.sbias = sbias;
@@ -343,8 +343,11 @@ extern "C" int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long
     if (Ho <= 0 || Wo <= 0 || (ldx % 8) || (lddy % 8) || ldx < Cin || lddy < Cout) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)x) | ((uintptr_t)dy)) & 15 || (((uintptr_t)dw) & 3)) return VT_ERR_BAD_ALIGN;
     const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
-    // + 256 bytes of slack: a ragged last column tile reads up to 254 bytes past the last row (zeros beyond the descriptor)
-    const long long xb = rows_in * ldx * 2, yb = rows_out * lddy * 2;
+    // The descriptors end with the LOGICAL end of the last row (its Cin / Cout columns, rounded up to a 16-byte chunk), not at
+    // rows * ld: when dy or x is a column slice of a wider buffer (the gradient of one half of a skip concatenation), rows * ld counted
+    // from the slice's base runs past the end of the allocation, and a ragged column tile of the last rows would read there -- an
+    // unmapped page when the allocation ends a segment (memory access fault seen at the full 320x512 size).  Past the descriptor: zeros.
+    const long long xb = ((rows_in - 1) * ldx + (Cin + 7) / 8 * 8) * 2, yb = ((rows_out - 1) * lddy + (Cout + 7) / 8 * 8) * 2;
     if (xb >= 0x7fffff00LL || yb >= 0x7fffff00LL) return VT_ERR_BAD_SHAPE;
     ConvDwParams p;
     p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw; p.lddy = lddy; p.ldx = ldx; p.dy_bytes = yb; p.x_bytes = xb;

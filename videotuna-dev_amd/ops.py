@@ -21,13 +21,19 @@ def _stream() -> int:
 
 
 # ---- optional per-kernel timing with HIP events recorded on the stream the kernels are launched on ----
-_PROFILE = {"on": False, "events": {}}
-_PROFILED = ("attn_fwd", "attn_bwd")
+_PROFILE = {"on": False, "events": {}, "work": {}}
+_PROFILED = ("attn_fwd", "attn_bwd", "conv", "conv_dw")
 
 
 def profile_reset(on: bool):
     _PROFILE["on"] = on
     _PROFILE["events"] = {}
+    _PROFILE["work"] = {}
+
+
+def profile_work():
+    """name -> algorithmic work (FLOPs) summed over the timed launches (kernels that report it: the UNet convolutions)"""
+    return dict(_PROFILE["work"])
 
 
 def profile_collect():
@@ -40,11 +46,14 @@ def profile_collect():
 
 
 class _timed:
-    def __init__(self, name):
+    def __init__(self, name, work: float = 0.0):
         self.name = name
+        self.work = work
 
     def __enter__(self):
         if _PROFILE["on"]:
+            if self.work:
+                _PROFILE["work"][self.name] = _PROFILE["work"].get(self.name, 0.0) + self.work
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record(torch.cuda.current_stream())
 
@@ -599,9 +608,10 @@ def conv_cl(x, wk, y, kernel, padding, stride: int = 1, bias=None, sbias=None, r
         _req(sbias, torch.float32, "sbias", 2)
         if sbias.shape[0] != N or sbias.shape[1] < Cout:
             raise ValueError(f"sbias must be [N, >=Cout], got {tuple(sbias.shape)}")
-    check(load_library().vt_conv_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), _p(sbias), 0 if sbias is None else sbias.stride(0),
-                                    _p(residual), 0 if residual is None else residual.stride(3), y.data_ptr(), y.stride(3),
-                                    N, T, H, W, Cin, Cout, KT, KH, KW, pt, ph, pw, stride, _stream()), "vt_conv_cl")
+    with _timed("conv", 2.0 * N * T * Ho * Wo * Cout * KT * KH * KW * Cin):
+        check(load_library().vt_conv_cl(x.data_ptr(), x.stride(3), wk.data_ptr(), _p(bias), _p(sbias), 0 if sbias is None else sbias.stride(0),
+                                        _p(residual), 0 if residual is None else residual.stride(3), y.data_ptr(), y.stride(3),
+                                        N, T, H, W, Cin, Cout, KT, KH, KW, pt, ph, pw, stride, _stream()), "vt_conv_cl")
     return y
 
 
@@ -615,8 +625,9 @@ def conv_dw_cl(dy, x, dw, kernel, padding, stride: int = 1, accumulate: bool = T
     if tuple(dw.shape) != (Cout, KT * KH * KW * Cin) or not dw.is_contiguous():
         raise ValueError(f"dw must be contiguous [{Cout}, {KT * KH * KW * Cin}], got {tuple(dw.shape)}")
     _cl_check(x, "x"); _cl_check(dy, "dy")
-    check(load_library().vt_conv_dw_cl(dy.data_ptr(), dy.stride(3), x.data_ptr(), x.stride(3), dw.data_ptr(), N, T, H, W, Cin, Cout,
-                                       KT, KH, KW, pt, ph, pw, stride, int(accumulate), _stream()), "vt_conv_dw_cl")
+    with _timed("conv_dw", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * Cout * KT * KH * KW * Cin):
+        check(load_library().vt_conv_dw_cl(dy.data_ptr(), dy.stride(3), x.data_ptr(), x.stride(3), dw.data_ptr(), N, T, H, W, Cin, Cout,
+                                           KT, KH, KW, pt, ph, pw, stride, int(accumulate), _stream()), "vt_conv_dw_cl")
 
 
 def linear_dw(dy, x, dw, accumulate: bool = True):

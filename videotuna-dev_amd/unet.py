@@ -362,6 +362,19 @@ def _packed(model: UNetModel) -> SimpleNamespace:
     return P
 
 
+_TRACE = {"f": None}
+
+
+def _trace_file():
+    import os
+    path = os.environ.get("VT_UNET_TRACE")
+    if not path:
+        return None
+    if _TRACE["f"] is None:
+        _TRACE["f"] = open(path, "a")
+    return _TRACE["f"]
+
+
 class _Var:
     """an activation [rows, C] (bf16, row stride may exceed C) and, during the backward pass, its gradient"""
     __slots__ = ("d", "g")
@@ -756,10 +769,15 @@ class _Run:
         shape = [B, T, H, W_]
         hs: List = []
 
+        trace = _trace_file()
+
         def run_layers(layers, h: _Var) -> _Var:
             nonlocal shape
             for l in layers:
                 Bq, Tq, Hq, Wq = shape
+                if trace is not None:
+                    torch.cuda.synchronize()
+                    trace.write(f"fwd {l.kind} {l.pre} shape {shape}\n"); trace.flush()
                 if l.kind == "conv_in":
                     y5 = self.conv(x64, l.pre + ".weight", l.pre + ".bias", (1, 3, 3), (0, 1, 1), wk=self.P.w["conv_in"])
                     h = _Var(y5.view(-1, l.cout))
@@ -840,6 +858,11 @@ class _Run:
         g = torch.zeros(B, T, H, W_, (Co + 7) // 8 * 8, dtype=BF16, device=self.dev)
         g[..., :Co] = dout.permute(0, 2, 3, 4, 1)
         self._dout5 = g[..., :Co]
+        trace = _trace_file()
         while self.tape:
-            self.tape.pop()()
+            fn = self.tape.pop()
+            fn()
+            if trace is not None:           # VT_UNET_TRACE=<file>: synchronise after every backward closure and log it (fault hunting)
+                torch.cuda.synchronize()
+                trace.write(f"bwd {len(self.tape)} {fn.__name__}\n"); trace.flush()
         self._dout5 = None

@@ -212,9 +212,9 @@ extern "C" int vt_conv_cl(const void* x, long long ldx, const void* wk, const vo
 // Weight gradient:  dW[co, tap, ci] (+)= sum_m dY[m, co] * x[shift(m, tap), ci]      (fp32, laid out like wk: [Cout, taps*Cin])
 // The reduction runs over the output positions m -- the slow index of both operands -- so, as in gemm_nt_bf16.hip, tiles are staged
 // row-major ([64 positions][128 channels], LDS-DMA, source-side swizzle) and both MFMA fragments come from transposed LDS reads
-// (ds_read_b64_tr_b16); the x rows of a K-tile are GATHERED: row m of the tile is the input position that tap (blockIdx.z) pairs
-// with output position m, or zeros.  P = Cout and Q = Cin need not be tile multiples: the columns past them hold whatever lies
-// next in memory, feed only accumulators that are never stored.  The position axis is split over blockIdx.y (fp32 atomics) until the
+// (ds_read_b64_tr_b16); the x rows of a K-tile are GATHERED: row m of the tile is the input position that the lane's tap pairs
+// with output position m, or zeros.  P = Cout and Q = taps * Cin need not be tile multiples: the columns past them hold whatever lies
+// next in memory (or zeros), feed only accumulators that are never stored.  The position axis is split over blockIdx.y (fp32 atomics) until the
 // grid fills the chip.  With one tap and no shift this is also the weight gradient of an nn.Linear whose dimensions are not
 // multiples of 128 (C = 320).
 struct ConvDwParams {
@@ -222,7 +222,18 @@ struct ConvDwParams {
     long long lddy, ldx, dy_bytes, x_bytes;
     int M, Cout, Cin, T, H, W, Ho, Wo, KT, KH, KW, pt, ph, pw, stride;
     int m_chunk, splits, accumulate;
+    // exact division of a 31-bit row index by Ho*Wo, Wo and T as multiply + shift (Granlund-Montgomery): the gather decodes four rows per
+    // lane and K-tile, and hardware integer division (~40 VALU instructions each, 6 per row) cost more than the K-tile's MFMAs
+    unsigned long long mg_hwo, mg_wo, mg_t;
+    int sh_hwo, sh_wo, sh_t;
 };
+__device__ __forceinline__ int cn_fastdiv(int n, unsigned long long magic, int shift) { return (int)(((unsigned long long)(unsigned)n * magic) >> shift); }
+static void cn_magic(int d, unsigned long long* magic, int* shift) {
+    int l = 0;
+    while ((1LL << l) < d) ++l;
+    *shift = 31 + l;
+    *magic = ((1ULL << *shift) + (unsigned long long)d - 1) / (unsigned long long)d;
+}
 typedef __attribute__((ext_vector_type(8))) short short8cn;
 __device__ __forceinline__ int cn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ bf16x8 cn_tr_pair(const char* p0, const char* p1) {
@@ -237,13 +248,14 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave & 1, wq = wave >> 1;
-    const int nbp = (p.Cout + 127) / 128, nbq = (p.Cin + 127) / 128;
+    const int ntaps = p.KT * p.KH * p.KW;
+    const int QF = ntaps * p.Cin;                    // the (tap, ci) axis flattened: a 128-column tile may straddle taps -- every lane
+                                                     // fetches ONE 8-channel chunk of one tap, so the gather is per lane anyway -- and only
+                                                     // the very last tile of the axis is ragged (Cin = 320: 23 tiles instead of 9 x 3)
+    const int nbp = (p.Cout + 127) / 128, nbq = (QF + 127) / 128;
     const int id = xcd_remap(blockIdx.x, nbp * nbq);
     const int tile_p = id % nbp, tile_q = id / nbp;
     const int p0 = tile_p * 128, q0 = tile_q * 128;
-    const int tap = blockIdx.z;
-    const int dw_ = tap % p.KW, dh = (tap / p.KW) % p.KH, dt = tap / (p.KW * p.KH);
-    const int ntaps = p.KT * p.KH * p.KW;
     const int HWo = p.Ho * p.Wo;
 
     const int m_lo = (int)blockIdx.y * p.m_chunk;
@@ -252,24 +264,40 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.dy, (unsigned)p.dy_bytes);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.x, (unsigned)p.x_bytes);
 
+    // lane l lands at (row l>>4 of its 4-row block, physical chunk l&15) and fetches logical chunk (l&15) ^ swz(row): its column, hence
+    // its tap and input-channel offset, are fixed for the whole kernel (per j: the row inside the K-tile changes the swizzle)
     const int drl = lane >> 4, dcp = lane & 15;
+    int a_col[4], b_ci[4], b_dt[4], b_dh[4], b_dw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * (wave + 4 * j) + drl;
+        const int ch = dcp ^ cn_swz(row);
+        a_col[j] = (p0 + ch * 8) * 2;
+        const int qc = q0 + ch * 8;
+        if (qc < QF) {
+            const int tap = qc / p.Cin;
+            b_ci[j] = (qc - tap * p.Cin) * 2;
+            b_dw[j] = tap % p.KW - p.pw; b_dh[j] = (tap / p.KW) % p.KH - p.ph; b_dt[j] = tap / (p.KW * p.KH) - p.pt;
+        } else {
+            b_ci[j] = -1; b_dw[j] = 0; b_dh[j] = 0; b_dt[j] = 0;
+        }
+    }
     auto dma = [&](int kt, int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 4 * (wave + 4 * j) + drl;
-            const int ch = dcp ^ cn_swz(row);
             const int ml = kt * 64 + row;
             const int m = m_lo + ml;
             unsigned a_off = CN_OOB, b_off = CN_OOB;
             if (ml < m_cnt) {
-                a_off = (unsigned)((long long)m * p.lddy * 2 + (p0 + ch * 8) * 2);
-                const int sp = m % HWo, nt = m / HWo;
-                const int t = nt % p.T, n = nt / p.T;
-                const int ho = sp / p.Wo, wo = sp - ho * p.Wo;
-                const int tt = t + dt - p.pt, hh = ho * p.stride + dh - p.ph, ww = wo * p.stride + dw_ - p.pw;
-                if (tt >= 0 && tt < p.T && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
+                a_off = (unsigned)((long long)m * p.lddy * 2 + a_col[j]);
+                const int nt = cn_fastdiv(m, p.mg_hwo, p.sh_hwo), sp = m - nt * HWo;
+                const int n = cn_fastdiv(nt, p.mg_t, p.sh_t), t = nt - n * p.T;
+                const int ho = cn_fastdiv(sp, p.mg_wo, p.sh_wo), wo = sp - ho * p.Wo;
+                const int tt = t + b_dt[j], hh = ho * p.stride + b_dh[j], ww = wo * p.stride + b_dw[j];
+                if (b_ci[j] >= 0 && tt >= 0 && tt < p.T && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
                     const long long r = (((long long)n * p.T + tt) * p.H + hh) * p.W + ww;
-                    b_off = (unsigned)(r * p.ldx * 2 + (q0 + ch * 8) * 2);
+                    b_off = (unsigned)(r * p.ldx * 2 + b_ci[j]);
                 }
             }
             char* dst = smem + buf * 32768 + (wave + 4 * j) * 1024;
@@ -313,7 +341,6 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
         __syncthreads();
     }
     const int fr = lane & 15;
-    const long long ldc = (long long)ntaps * p.Cin;
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
@@ -322,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
             for (int rg = 0; rg < 4; ++rg) {
                 const int pr = p0 + wp * 64 + tp * 16 + 4 * g + rg;
                 const int qc = q0 + wq * 64 + tq * 16 + fr;
-                if (pr < p.Cout && qc < p.Cin) {
-                    float* c = p.dw + (size_t)pr * ldc + (size_t)tap * p.Cin + qc;
+                if (pr < p.Cout && qc < QF) {
+                    float* c = p.dw + (size_t)pr * QF + qc;
                     const float v = acc[tp][tq][rg];
                     if (p.splits > 1 || p.accumulate) atomicAdd(c, v);
                     else *c = v;
@@ -332,15 +359,15 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
 }
 
 // dy: bf16 [N,T,Ho,Wo,Cout] (position stride lddy), x: bf16 [N,T,H,W,Cin] (ldx), dw: fp32 [Cout, taps*Cin].  accumulate != 0: dw +=
-// (gradient accumulation over micro-batches); otherwise dw is overwritten.  ldx % 8 == 0, lddy % 8 == 0 (16-byte rows; Cin / Cout themselves
-// are free: 4 output channels live in an 8-wide buffer), both tensors < 2 GiB.
+// (gradient accumulation over micro-batches); otherwise dw is overwritten.  Cin % 8 == 0, ldx % 8 == 0, lddy % 8 == 0 (16-byte rows; Cout itself
+// is free: 4 output channels live in an 8-wide buffer), both tensors < 2 GiB.
 extern "C" int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long long ldx, float* dw,
                              int N, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int pt, int ph, int pw, int stride,
                              int accumulate, void* stream) {
     if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VT_ERR_BAD_SHAPE;
     if (KT < 1 || KH < 1 || KW < 1 || stride < 1 || pt < 0 || ph < 0 || pw < 0 || 2 * pt != KT - 1) return VT_ERR_BAD_SHAPE;
     const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
-    if (Ho <= 0 || Wo <= 0 || (ldx % 8) || (lddy % 8) || ldx < Cin || lddy < Cout) return VT_ERR_BAD_SHAPE;
+    if (Ho <= 0 || Wo <= 0 || (ldx % 8) || (lddy % 8) || ldx < Cin || lddy < Cout || (Cin % 8)) return VT_ERR_BAD_SHAPE;    // a 16-byte chunk must stay inside one tap
     if ((((uintptr_t)x) | ((uintptr_t)dy)) & 15 || (((uintptr_t)dw) & 3)) return VT_ERR_BAD_ALIGN;
     const long long rows_in = (long long)N * T * H * W, rows_out = (long long)N * T * Ho * Wo;
     // The descriptors end with the LOGICAL end of the last row (its Cin / Cout columns, rounded up to a 16-byte chunk), not at
@@ -354,13 +381,13 @@ extern "C" int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long
     p.M = (int)rows_out; p.Cout = Cout; p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
     p.KT = KT; p.KH = KH; p.KW = KW; p.pt = pt; p.ph = ph; p.pw = pw; p.stride = stride; p.accumulate = accumulate;
     const int taps = KT * KH * KW;
-    const int tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    const int tiles = ((Cout + 127) / 128) * ((taps * Cin + 127) / 128);
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    long long want = (2LL * cus + (long long)tiles * taps - 1) / ((long long)tiles * taps);       // ~2 workgroups per CU
+    long long want = (2LL * cus + (long long)tiles - 1) / (long long)tiles;                       // ~2 workgroups per CU
     long long maxs = (rows_out + 511) / 512;                                                       // >= 8 K-tiles per workgroup
     int splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     if (splits < 1) splits = 1;
@@ -368,10 +395,11 @@ extern "C" int vt_conv_dw_cl(const void* dy, long long lddy, const void* x, long
     chunk = (chunk + 63) / 64 * 64;
     splits = (int)((rows_out + chunk - 1) / chunk);
     p.m_chunk = chunk; p.splits = splits;
+    cn_magic(Ho * Wo, &p.mg_hwo, &p.sh_hwo); cn_magic(Wo, &p.mg_wo, &p.sh_wo); cn_magic(T, &p.mg_t, &p.sh_t);
     hipStream_t st = (hipStream_t)stream;
     if (splits > 1 && !accumulate) {
         if (hipMemsetAsync(dw, 0, (size_t)Cout * taps * Cin * 4, st) != hipSuccess) return VT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(conv_dw_kernel, dim3(tiles, splits, taps), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_dw_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

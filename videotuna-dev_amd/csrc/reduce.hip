@@ -95,6 +95,13 @@ extern "C" int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, c
     static int slices_env = -1;
     if (slices_env < 0) { const char* e = getenv("VT_RD_SLICES"); slices_env = e ? atoi(e) : 0; }
     int slices = slices_env > 0 ? slices_env : RD_SLICES;
+    if (slices_env <= 0) {
+        // ~160 rows per slice: 256 slices at the DiT's 35 552 rows (the measured optimum above), 1024 at the 163 840 rows of the UNet's
+        // first level, where 256 slices on a 320-column matrix were 2 waves per CU (70 us for 105 MB)
+        long long want = M / 160;
+        if (want > 2048) want = 2048;
+        if (want > slices) slices = (int)want;
+    }
     if (slices > M) slices = (int)M;
     p.rows_per_slice = (int)((M + slices - 1) / slices);
     dim3 grid((D + 511) / 512, slices);
@@ -212,41 +219,43 @@ extern "C" int vt_ln_param_combine(const float* G1, const float* G2, int G, int 
 // ------------------------------------------------------------------------------------------------
 // backward of a Linear applied to a handful of rows (the time-embedding / adaLN MLPs see one row per sample):
 //   dW[n,k] += sum_b dy[b,n] x[b,k] ;  db[n] += sum_b dy[b,n] ;  dx[b,k] += sum_n dy[b,n] W[n,k]      (Bn <= 8)
-// dy fp32 [Bn, ldy], x bf16 [Bn, ldx], W bf16 [N, K].  One block per 64 output rows n.
+// dy fp32 [Bn, ldy], x bf16 [Bn, ldx], W bf16 [N, K].  One block per 16 output rows n and 256 columns k.
 // ------------------------------------------------------------------------------------------------
 #define SL_MAXB 8
+#define SL_ROWS 16     // output rows per block; blockIdx.y walks K in chunks of 256 (r02: one block per 64 rows was 5 blocks for a
+                       // 320 x 1280 weight -- 368 us per call, 26 calls per VideoCrafter2 step)
 __global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* dy, int ldy, const bf16_t* x, int ldx, const bf16_t* W,
                                                               float* dW, float* db, float* dx, int lddx, int Bn, int N, int K) {
-    const int n0 = blockIdx.x * 64;
+    const int n0 = blockIdx.x * SL_ROWS;
     const int tid = threadIdx.x;
-    __shared__ float sdy[SL_MAXB][64];
-    for (int i = tid; i < Bn * 64; i += 256) {
-        const int b = i >> 6, nn = i & 63;
+    __shared__ float sdy[SL_MAXB][SL_ROWS];
+    for (int i = tid; i < Bn * SL_ROWS; i += 256) {
+        const int b = i / SL_ROWS, nn = i % SL_ROWS;
         sdy[b][nn] = (n0 + nn < N) ? dy[(size_t)b * ldy + n0 + nn] : 0.f;
     }
     __syncthreads();
-    if (db != nullptr && tid < 64 && n0 + tid < N) {
+    if (db != nullptr && blockIdx.y == 0 && tid < SL_ROWS && n0 + tid < N) {
         float s = 0.f;
         for (int b = 0; b < Bn; ++b) s += sdy[b][tid];
         db[n0 + tid] += s;
     }
-    for (int k = tid; k < K; k += 256) {
-        float xv[SL_MAXB], dxa[SL_MAXB];
-        for (int b = 0; b < Bn; ++b) { xv[b] = bf2f(x[(size_t)b * ldx + k]); dxa[b] = 0.f; }
-        for (int nn = 0; nn < 64 && n0 + nn < N; ++nn) {
-            const float w = bf2f(W[(size_t)(n0 + nn) * K + k]);
-            float g = 0.f;
-            for (int b = 0; b < Bn; ++b) { g += sdy[b][nn] * xv[b]; dxa[b] += sdy[b][nn] * w; }
-            if (dW != nullptr) dW[(size_t)(n0 + nn) * K + k] += g;
-        }
-        if (dx != nullptr)
-            for (int b = 0; b < Bn; ++b) atomicAdd(dx + (size_t)b * lddx + k, dxa[b]);
+    const int k = blockIdx.y * 256 + tid;
+    if (k >= K) return;
+    float xv[SL_MAXB], dxa[SL_MAXB];
+    for (int b = 0; b < Bn; ++b) { xv[b] = bf2f(x[(size_t)b * ldx + k]); dxa[b] = 0.f; }
+    for (int nn = 0; nn < SL_ROWS && n0 + nn < N; ++nn) {
+        const float w = bf2f(W[(size_t)(n0 + nn) * K + k]);
+        float g = 0.f;
+        for (int b = 0; b < Bn; ++b) { g += sdy[b][nn] * xv[b]; dxa[b] += sdy[b][nn] * w; }
+        if (dW != nullptr) dW[(size_t)(n0 + nn) * K + k] += g;
     }
+    if (dx != nullptr)
+        for (int b = 0; b < Bn; ++b) atomicAdd(dx + (size_t)b * lddx + k, dxa[b]);
 }
 extern "C" int vt_small_linear_bwd(const float* dy, int ldy, const void* x, int ldx, const void* W, float* dW, float* db,
                                    float* dx, int lddx, int Bn, int N, int K, void* stream) {
     if (Bn <= 0 || Bn > SL_MAXB || N <= 0 || K <= 0) return VT_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, ldy, (const bf16_t*)x, ldx,
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((N + SL_ROWS - 1) / SL_ROWS, (K + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, ldy, (const bf16_t*)x, ldx,
                        (const bf16_t*)W, dW, db, dx, lddx, Bn, N, K);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

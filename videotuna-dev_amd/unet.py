@@ -603,8 +603,13 @@ class _Run:
         g2 = g5.as_strided((g5.shape[0] * g5.shape[1] * g5.shape[2] * g5.shape[3], Cout), (g5.stride(3), 1))      # rows x channels view (row stride may exceed Cout)
         ops.group_colsum(g2, self.G(bname), D=Cout)
         dw = self.G(wname)
-        xs = x5 if cin_true is None else x5[..., :cin_true]
-        ops.conv_dw_cl(g5, xs, dw, kernel, padding, stride, accumulate=True)
+        if cin_true is None:
+            ops.conv_dw_cl(g5, x5, dw, kernel, padding, stride, accumulate=True)
+        else:      # conv_in: 4 real input channels; the kernel wants whole 16-byte chunks per tap -> gradient against 8 channels, 4 kept
+            taps = kernel[0] * kernel[1] * kernel[2]
+            tmp = torch.empty(Cout, taps * 8, dtype=F32, device=self.dev)
+            ops.conv_dw_cl(g5, x5[..., :8], tmp, kernel, padding, stride, accumulate=False)
+            dw.view(Cout, taps, cin_true).add_(tmp.view(Cout, taps, 8)[..., :cin_true])
         if not need_dx:
             return None
         B, T, H, W_, Cin = x5.shape

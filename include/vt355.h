@@ -314,6 +314,21 @@ int vt_attn_small_bwd(const void* q, const void* k, const void* v, const void* o
                       long long o_rs, long long o_bs, long long do_rs, long long do_bs, long long dq_rs, long long dq_bs,
                       long long dk_rs, long long dv_rs, float softmax_scale, int mask_block, void* stream);
 
+/* Flash attention for head dimensions other than 64 (csrc/attn_gen.hip): head_dim 80 (OpenSora STDiT's 72, zero padded: 16 heads x 72,
+ * opensora/models/layers/blocks.py:139-225 `Attention` and :472-505 `MultiHeadCrossAttention`) or 128 (HunyuanVideo,
+ * hunyuan/hyvideo_t2v/modules/attenion.py:60-156).  Element (item b, row s, head h, d) at base + b*bs + s*rs + h*hstride + d.
+ * kv_len: int32 [NB] valid keys per item (the BlockDiagonalMask.from_seqlens([N]*B, y_lens) text mask, blocks.py:497-500) | NULL.
+ * mask_block = T > 0: packed sequences of T rows in one row space (STDiT's 16-frame temporal attention), NB = 1, Sk = Sq.
+ * lse2 fp32 [NB, H, Sq].  Backward: dq bf16 like q; packed: dk, dv bf16; otherwise dk32, dv32 fp32 [NB, Sk, dk_rs] ZEROED BY THE CALLER. */
+int vt_attn_gen_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* kv_len, int head_dim, int hstride,
+                    int NB, int H, int Sq, int Sk, long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs,
+                    long long v_bs, long long o_rs, long long o_bs, float softmax_scale, int mask_block, void* stream);
+int vt_attn_gen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
+                    void* dq, void* dk, void* dv, float* dk32, float* dv32, int head_dim, int hstride, int NB, int H, int Sq, int Sk,
+                    long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs, long long v_bs,
+                    long long o_rs, long long o_bs, long long do_rs, long long do_bs, long long dq_rs, long long dq_bs,
+                    long long dk_rs, long long dv_rs, float softmax_scale, int mask_block, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,3 +248,65 @@ def test_attn_small_packed_sequences(dev, R, T, H):
     close(o[0, rows], ref.permute(0, 2, 1, 3).reshape(n * T, D), 2e-2, 1e-2, "temporal attention output")
     gref = x.grad.permute(1, 3, 0, 2, 4).reshape(n * T, 3 * D)
     close(dqkv[0, rows], gref, 3e-2, 2e-2 * gref.abs().max().item(), "temporal attention dqkv")
+
+
+# ------------------------------------------------------------------------------------------------ generic-head-dim attention
+def _gen_case(dev, NB, H, Sq, Sk, hd, hstride, kv_len=None, mask_block=0, seed=0):
+    from vt355 import ops
+    g = torch.Generator().manual_seed(seed + Sq + Sk + hd)
+    hp = 80 if hd == 72 else 128
+    def mk(S):
+        t = torch.zeros(NB, S, H, hstride)
+        t[..., :hd] = torch.randn(NB, S, H, hd, generator=g)
+        return rb(t)
+    q, k, v, do = mk(Sq), mk(Sk), mk(Sk), mk(Sq)
+    scale = hd ** -0.5
+    qr, kr, vr = [t[..., :hd].double().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v)]
+    s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    if kv_len is not None:
+        for b, n in enumerate(kv_len):
+            s[b, :, :, n:] = float("-inf")
+    if mask_block:
+        i = torch.arange(Sq)[:, None] // mask_block; j = torch.arange(Sk)[None, :] // mask_block
+        s = s.masked_fill(i != j, float("-inf"))
+    ref = torch.einsum("bhij,bhjd->bhid", s.softmax(-1), vr)
+    (ref * do[..., :hd].double().permute(0, 2, 1, 3)).sum().backward()
+    D = H * hstride
+    fl = lambda t: t.reshape(NB, -1, D).to(dev, BF)
+    qd, kd, vd, dod = fl(q), fl(k), fl(v), fl(do)
+    o = torch.zeros(NB, Sq, D, dtype=BF, device=dev); lse = torch.empty(NB, H, Sq, device=dev)
+    kl = None if kv_len is None else torch.tensor(kv_len, dtype=torch.int32, device=dev)
+    ops.attn_gen_fwd(qd, kd, vd, o, lse, H, hp, hstride, scale, kv_len=kl, mask_block=mask_block)
+    un = lambda t: t.view(NB, -1, H, hstride)[..., :hd].permute(0, 2, 1, 3)
+    close(un(o), ref, 2e-2, 1e-2, "attention output")
+    dq = torch.zeros(NB, Sq, D, dtype=BF, device=dev)
+    if mask_block:
+        dk = torch.zeros(NB, Sk, D, dtype=BF, device=dev); dv = torch.zeros(NB, Sk, D, dtype=BF, device=dev)
+    else:
+        dk = torch.empty(NB, Sk, D, device=dev); dv = torch.empty(NB, Sk, D, device=dev)
+    ops.attn_gen_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, H, hp, hstride, scale, kv_len=kl, mask_block=mask_block)
+    for got, r, nm in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+        close(un(got), r, 3e-2, 2e-2 * r.abs().max().item(), "attention " + nm)
+
+
+@pytest.mark.parametrize("NB,H,Sq,Sk", [(3, 2, 256, 256), (2, 3, 100, 77), (1, 16, 64, 64)])
+def test_attn_gen_hd72(dev, NB, H, Sq, Sk):
+    """STDiT spatial self-attention (blocks.py:139-225): 16 heads x 72, stored 80 wide"""
+    _gen_case(dev, NB, H, Sq, Sk, 72, 80)
+
+
+def test_attn_gen_hd72_varlen_text(dev):
+    """STDiT MultiHeadCrossAttention (blocks.py:472-505): every sample's queries against ITS first y_len text tokens"""
+    _gen_case(dev, 3, 2, 300, 120, 72, 80, kv_len=[20, 120, 1])
+
+
+@pytest.mark.parametrize("R,T", [(256, 16), (80, 16), (72, 8)])
+def test_attn_gen_hd72_packed_temporal(dev, R, T):
+    """STDiT temporal attention: R / T consecutive 16-frame sequences in one row space"""
+    _gen_case(dev, 1, 4, R, R, 72, 80, mask_block=T)
+
+
+@pytest.mark.parametrize("NB,H,Sq,Sk", [(1, 2, 300, 300), (2, 1, 130, 47)])
+def test_attn_gen_hd128(dev, NB, H, Sq, Sk):
+    """HunyuanVideo's head size (hyvideo_t2v/modules/attenion.py:60-156), short sequences"""
+    _gen_case(dev, NB, H, Sq, Sk, 128, 128)

@@ -1,0 +1,386 @@
+// Flash attention for head dimensions other than 64 (template HD: 80 = OpenSora STDiT's 72 padded to five 16-wide MFMA k-steps,
+// 128 = HunyuanVideo), any query / key length, per-item key lengths (padded text), optional packed block-diagonal sequences; forward and
+// backward, gfx950.  The next-scope rows of SURVEY 8(a): a14 (STDiT: videotuna/models/opensora/models/layers/blocks.py:139-225
+// `Attention` -- spatial 256-token and temporal 16-token sequences of 16 heads x 72 -- and :472-505 `MultiHeadCrossAttention`, the
+// xformers BlockDiagonalMask.from_seqlens([N]*B, y_lens) varlen text attention) and a16 (hunyuan hyvideo_t2v/modules/attenion.py:60-156,
+// 24 heads x 128).
+//
+// One wave owns 32 queries of one (item, head); the four waves of a workgroup share the key tiles (32 keys) that the workgroup
+// stages in LDS one at a time.  Forward: S^T = K Q^T (lane = query -> the online-softmax statistics are lane-local + one cross-half
+// shuffle), O += P V with P taken from the S^T accumulators as the A operand and V^T read from a transposed LDS image.  Backward:
+// S = Q K^T and dP = dO V^T with the KEY on the lane, so that P^T and dS^T feed dV += P^T dO and dK += dS^T Q straight from the
+// registers (B operands: transposed per-wave images of the wave's Q / dO tile); dS crosses the wave's LDS once for dQ += dS K, which
+// stays in registers over the whole key loop; the per-(query tile, key tile) dK / dV contributions go to fp32 accumulators with
+// atomics (few query tiles per key at STDiT's sizes: 8 for the 256-token spatial attention), or straight to bf16 in packed mode
+// where a tile meets only itself.  A simple, correct kernel for sequences of tens to thousands of tokens -- NOT the long-sequence
+// kernel of the CogVideoX path (attn_fwd.hip / attn_bwd.hip, head_dim 64).
+#include "common.h"
+
+struct AttnGenParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* dout;
+    bf16_t* out; float* lse2;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv; float* dk32; float* dv32;
+    const int* kv_len;       // [NB] valid keys per item (NULL: Sk)
+    long long q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs, do_rs, do_bs, dq_rs, dq_bs, dk_rs, dk_bs, dv_rs, dv_bs;
+    int NB, H, Sq, Sk, mask_block, hstride;      // hstride: elements between consecutive heads of a row (>= HD)
+    float scale, scale2;
+};
+
+__device__ __forceinline__ int ag_crow(int r, int hh) { return ((r >> 2) << 3) + (hh << 2) + (r & 3); }
+__device__ __forceinline__ bf16x8 ag_pack8(const f32x16& a, int s2) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)a[8 * s2 + e];
+    return o;
+}
+__device__ __forceinline__ bf16x8 ag_tfrag(const char* row, int s2, int hh) {
+    const u32x2 lo = *(const u32x2*)(row + ((2 * s2) * 8 + 4 * hh) * 2);
+    const u32x2 hi = *(const u32x2*)(row + ((2 * s2 + 1) * 8 + 4 * hh) * 2);
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#define AG_TROW 80           // bytes per row of a transposed [d][32 + 8] image
+
+// stage key tile kt (32 keys) of (item, head): K row-major, optionally V row-major, K^T, V^T.  Rows >= nk and d >= HD are zeros.
+template <int HD, bool VROW, bool KT_, bool VT_>
+__device__ __forceinline__ void ag_stage(const AttnGenParams& p, const bf16_t* kb, const bf16_t* vb, int key0, int nk, char* Ks, char* Vs, char* Kt,
+                                         char* Vt) {
+    constexpr int KROW = HD * 2 + 16;
+    constexpr int NCH = HD / 8;
+    constexpr int DT = (HD + 31) / 32 * 32;
+    for (int i = threadIdx.x; i < 32 * NCH; i += 256) {
+        const int kl = i / NCH, ch = i - kl * NCH;
+        u32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (key0 + kl < nk) {
+            kk = *(const u32x4*)(kb + (long long)(key0 + kl) * p.k_rs + ch * 8);
+            vv = *(const u32x4*)(vb + (long long)(key0 + kl) * p.v_rs + ch * 8);
+        }
+        *(u32x4*)(Ks + kl * KROW + ch * 16) = kk;
+        if (VROW) *(u32x4*)(Vs + kl * KROW + ch * 16) = vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (KT_) *(unsigned short*)(Kt + (ch * 8 + e) * AG_TROW + kl * 2) = (unsigned short)((kk[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            if (VT_) *(unsigned short*)(Vt + (ch * 8 + e) * AG_TROW + kl * 2) = (unsigned short)((vv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+    }
+    if (DT > HD) {          // the d rows past HD of the transposed images feed the last (half-empty) 32-wide d-tile: zeros
+        for (int i = threadIdx.x; i < (DT - HD) * 32; i += 256) {
+            const int d = HD + i / 32, kl = i % 32;
+            if (KT_) *(unsigned short*)(Kt + d * AG_TROW + kl * 2) = 0;
+            if (VT_) *(unsigned short*)(Vt + d * AG_TROW + kl * 2) = 0;
+        }
+    }
+}
+
+// ============================================================================================================ forward
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_gen_fwd_kernel(AttnGenParams p) {
+    constexpr int KS = HD / 16, NDT = (HD + 31) / 32, KROW = HD * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char Ks[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char Vt[NDT * 32 * AG_TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, item = blockIdx.z;
+    const bool masked = p.mask_block > 0;
+    const int q0 = blockIdx.x * 128;
+    const int nk = masked ? p.Sq : (p.kv_len ? p.kv_len[item] : p.Sk);
+    const long long ib = masked ? 0 : item;
+    const bf16_t* kb = p.k + ib * p.k_bs + (long long)h * p.hstride;
+    const bf16_t* vb = p.v + ib * p.v_bs + (long long)h * p.hstride;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qi = q0 + wave * 32 + ql;
+    const bool qok = qi < p.Sq;
+    const bf16_t* qp = p.q + ib * p.q_bs + (long long)qi * p.q_rs + (long long)h * p.hstride;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (qok) t = *(const u32x4*)(qp + ks * 16 + hh * 8);
+        qf[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float mx = -1e30f, sum = 0.f;
+    // key tiles this workgroup must visit: all of them, or (packed mode) only the tiles its own 128 rows live in
+    const int kt_lo = masked ? q0 / 32 : 0;
+    const int kt_hi = masked ? min((q0 + 128 + 31) / 32, (nk + 31) / 32) : (nk + 31) / 32;
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        __syncthreads();
+        ag_stage<HD, false, false, true>(p, kb, vb, kt * 32, nk, Ks, nullptr, nullptr, Vt);
+        __syncthreads();
+        if (masked && kt != q0 / 32 + wave) continue;          // a packed tile meets only itself (32 % mask_block == 0)
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + ql * KROW + ks * 32 + hh * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        float tmx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kl = ag_crow(r, hh);
+            bool ok = kt * 32 + kl < nk;
+            if (masked) ok = ok && (kl / p.mask_block == ql / p.mask_block);
+            s[r] = ok ? s[r] * p.scale2 : -1e30f;
+            tmx = fmaxf(tmx, s[r]);
+        }
+        tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+        const float nmx = fmaxf(mx, tmx);
+        const float corr = __builtin_amdgcn_exp2f(mx - nmx);
+        float ts = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = s[r] > -1e29f ? __builtin_amdgcn_exp2f(s[r] - nmx) : 0.f;
+            s[r] = e;
+            ts += e;
+        }
+        ts += __shfl_xor(ts, 32, 64);
+        sum = sum * corr + ts;
+        mx = nmx;
+        // O rows are queries = C-register rows: the per-query correction lives on the lane of that query -> fetch it per register row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float cr = __shfl(corr, ag_crow(r, hh), 64);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt][r] *= cr;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = ag_pack8(s, s2);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 vf = ag_tfrag(Vt + (dt * 32 + ql) * AG_TROW, s2, hh);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, vf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    if (hh == 0 && qok && p.lse2 != nullptr) p.lse2[((long long)ib * p.H + h) * p.Sq + qi] = mx + __builtin_amdgcn_logf(sum);
+    bf16_t* ob = p.out + ib * p.o_bs + (long long)h * p.hstride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = q0 + wave * 32 + ag_crow(r, hh);
+        const float ir = __shfl(inv, ag_crow(r, hh), 64);
+        if (qr < p.Sq) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int d = dt * 32 + ql;
+                if (d < HD) ob[(long long)qr * p.o_rs + d] = (bf16_t)(o[dt][r] * ir);
+            }
+        }
+    }
+}
+
+// ============================================================================================================ backward
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_gen_bwd_kernel(AttnGenParams p) {
+    constexpr int KS = HD / 16, NDT = (HD + 31) / 32, KROW = HD * 2 + 16, DT = NDT * 32;
+    __shared__ __attribute__((aligned(16))) char Ks[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char Vs[32 * KROW];
+    __shared__ __attribute__((aligned(16))) char Kt[DT * AG_TROW];
+    __shared__ __attribute__((aligned(16))) char Wv[4][2 * DT * AG_TROW + 32 * AG_TROW + 256];     // per wave: Q^T | dO^T | dS | lse, delta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, item = blockIdx.z;
+    const bool masked = p.mask_block > 0;
+    const int q0 = blockIdx.x * 128;
+    const int nk = masked ? p.Sq : (p.kv_len ? p.kv_len[item] : p.Sk);
+    const long long ib = masked ? 0 : item;
+    const bf16_t* kb = p.k + ib * p.k_bs + (long long)h * p.hstride;
+    const bf16_t* vb = p.v + ib * p.v_bs + (long long)h * p.hstride;
+    const int ql = lane & 31, hh = lane >> 5;
+    char* Qt = Wv[wave];
+    char* dOt = Qt + DT * AG_TROW;
+    char* dSs = dOt + DT * AG_TROW;
+    float* stat = (float*)(dSs + 32 * AG_TROW);
+    const int qi = q0 + wave * 32 + ql;
+    const bool qok = qi < p.Sq;
+    bf16x8 qf[KS], dof[KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        u32x4 tq = {0u, 0u, 0u, 0u}, td = {0u, 0u, 0u, 0u}, to = {0u, 0u, 0u, 0u};
+        if (qok) {
+            const long long ho = (long long)h * p.hstride + ks * 16 + hh * 8;
+            tq = *(const u32x4*)(p.q + ib * p.q_bs + (long long)qi * p.q_rs + ho);
+            td = *(const u32x4*)(p.dout + ib * p.do_bs + (long long)qi * p.do_rs + ho);
+            to = *(const u32x4*)(p.o + ib * p.o_bs + (long long)qi * p.o_rs + ho);
+        }
+        qf[ks] = __builtin_bit_cast(bf16x8, tq);
+        dof[ks] = __builtin_bit_cast(bf16x8, td);
+        float a[8], b[8];
+        unpack8(td, a); unpack8(to, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dl += a[e] * b[e];
+            const int d = ks * 16 + hh * 8 + e;
+            *(unsigned short*)(Qt + d * AG_TROW + ql * 2) = (unsigned short)((tq[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            *(unsigned short*)(dOt + d * AG_TROW + ql * 2) = (unsigned short)((td[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+    }
+    if (DT > HD) {
+        for (int i = lane; i < (DT - HD) * 32; i += 64) {
+            const int d = HD + i / 32, c = i % 32;
+            *(unsigned short*)(Qt + d * AG_TROW + c * 2) = 0;
+            *(unsigned short*)(dOt + d * AG_TROW + c * 2) = 0;
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (hh == 0) {
+        stat[ql] = qok ? p.lse2[((long long)ib * p.H + h) * p.Sq + qi] : 0.f;
+        stat[32 + ql] = dl;
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 dQ[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dQ[dt][e] = 0.f;
+
+    const int kt_lo = masked ? q0 / 32 : 0;
+    const int kt_hi = masked ? min((q0 + 128 + 31) / 32, (nk + 31) / 32) : (nk + 31) / 32;
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        __syncthreads();
+        ag_stage<HD, true, true, false>(p, kb, vb, kt * 32, nk, Ks, Vs, Kt, nullptr);
+        __syncthreads();
+        if (masked && kt != q0 / 32 + wave) continue;
+        if (q0 + wave * 32 >= p.Sq) continue;
+        f32x16 S, dP;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { S[e] = 0.f; dP[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + ql * KROW + ks * 32 + hh * 16);
+            const bf16x8 vf = *(const bf16x8*)(Vs + ql * KROW + ks * 32 + hh * 16);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf, S, 0, 0, 0);            // [query rows][key cols]
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[ks], vf, dP, 0, 0, 0);
+        }
+        const int key = kt * 32 + ql;
+        const bool kok = key < nk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = ag_crow(r, hh);
+            bool ok = kok && (q0 + wave * 32 + qr) < p.Sq;
+            if (masked) ok = ok && (ql / p.mask_block == qr / p.mask_block);
+            const float pr = ok ? __builtin_amdgcn_exp2f(S[r] * p.scale2 - stat[qr]) : 0.f;
+            S[r] = pr;
+            dP[r] = pr * (dP[r] - stat[32 + qr]) * p.scale;
+            *(unsigned short*)(dSs + qr * AG_TROW + ql * 2) = __builtin_bit_cast(unsigned short, (bf16_t)dP[r]);
+        }
+        // dV[32 keys][HD] = P^T dO ; dK = dS^T Q : straight to memory (few query tiles per key at these sizes)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            f32x16 aV, aK;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { aV[e] = 0.f; aK[e] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = ag_pack8(S, s2), dsf = ag_pack8(dP, s2);
+                const bf16x8 dob = ag_tfrag(dOt + (dt * 32 + ql) * AG_TROW, s2, hh);
+                const bf16x8 qb = ag_tfrag(Qt + (dt * 32 + ql) * AG_TROW, s2, hh);
+                aV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, dob, aV, 0, 0, 0);
+                aK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, qb, aK, 0, 0, 0);
+            }
+            const int d = dt * 32 + ql;
+            if (d < HD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kr = kt * 32 + ag_crow(r, hh);
+                    if (kr >= nk) continue;
+                    const long long col = (long long)h * p.hstride + d;
+                    if (masked) {
+                        p.dk[(long long)kr * p.dk_rs + col] = (bf16_t)aK[r];
+                        p.dv[(long long)kr * p.dv_rs + col] = (bf16_t)aV[r];
+                    } else {
+                        atomicAdd(p.dk32 + ((long long)item * p.Sk + kr) * p.dk_rs + col, aK[r]);
+                        atomicAdd(p.dv32 + ((long long)item * p.Sk + kr) * p.dv_rs + col, aV[r]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dQ += dS K_tile
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 af = *(const bf16x8*)(dSs + ql * AG_TROW + (s * 16 + hh * 8) * 2);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 bfk = *(const bf16x8*)(Kt + (dt * 32 + ql) * AG_TROW + (s * 16 + hh * 8) * 2);
+                dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfk, dQ[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        const int d = dt * 32 + ql;
+        if (d >= HD) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = q0 + wave * 32 + ag_crow(r, hh);
+            if (qr < p.Sq) p.dq[ib * p.dq_bs + (long long)qr * p.dq_rs + (long long)h * p.hstride + d] = (bf16_t)dQ[dt][r];
+        }
+    }
+}
+
+static int ag_check(int head_dim, int NB, int H, int Sq, int Sk, int mask_block, int hstride, const long long* st, int n) {
+    if (head_dim != 80 && head_dim != 128) return VT_ERR_UNSUPPORTED;
+    if (NB <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || hstride < head_dim || (hstride % 8)) return VT_ERR_BAD_SHAPE;
+    if (mask_block < 0 || (mask_block > 0 && (32 % mask_block))) return VT_ERR_BAD_SHAPE;
+    for (int i = 0; i < n; ++i)
+        if (st[i] % 8) return VT_ERR_BAD_SHAPE;
+    return VT_OK;
+}
+
+// Element (item b, row s, head h, d) at base + b*bs + s*rs + h*hstride + d, d < head_dim (80 | 128; a 72-wide head is stored 80 wide, zero
+// padded -- pad the projection weights).  kv_len: int32 [NB] valid keys per item (the padded-text mask of STDiT's cross-attention) | NULL.
+// mask_block = T > 0: q, k, v, o are ONE row space of Sq rows = consecutive sequences of T rows (NB = 1, Sk = Sq, batch strides ignored).
+// lse2: fp32 [NB, H, Sq].
+extern "C" int vt_attn_gen_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* kv_len, int head_dim, int hstride,
+                               int NB, int H, int Sq, int Sk, long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs,
+                               long long v_bs, long long o_rs, long long o_bs, float softmax_scale, int mask_block, void* stream) {
+    const long long st[8] = {q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs};
+    int rc = ag_check(head_dim, NB, H, Sq, Sk, mask_block, hstride, st, 8);
+    if (rc != VT_OK) return rc;
+    if (mask_block > 0 && (NB != 1 || Sk != Sq)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return VT_ERR_BAD_ALIGN;
+    AttnGenParams p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse2 = lse2; p.kv_len = kv_len;
+    p.q_rs = q_rs; p.q_bs = q_bs; p.k_rs = k_rs; p.k_bs = k_bs; p.v_rs = v_rs; p.v_bs = v_bs; p.o_rs = o_rs; p.o_bs = o_bs;
+    p.NB = NB; p.H = H; p.Sq = Sq; p.Sk = Sk; p.mask_block = mask_block; p.hstride = hstride;
+    p.scale = softmax_scale; p.scale2 = softmax_scale * 1.4426950408889634f;
+    const dim3 grid((Sq + 127) / 128, H, mask_block > 0 ? 1 : NB);
+    if (head_dim == 80) hipLaunchKernelGGL(attn_gen_fwd_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_gen_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// dq bf16 like q.  mask_block > 0: dk, dv bf16 in the k / v row space.  mask_block == 0: dk32, dv32 fp32 [NB, Sk, dk_rs] accumulators ZEROED
+// BY THE CALLER (dk_rs = their row stride, heads at h*hstride like k).
+extern "C" int vt_attn_gen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
+                               void* dq, void* dk, void* dv, float* dk32, float* dv32, int head_dim, int hstride, int NB, int H, int Sq, int Sk,
+                               long long q_rs, long long q_bs, long long k_rs, long long k_bs, long long v_rs, long long v_bs,
+                               long long o_rs, long long o_bs, long long do_rs, long long do_bs, long long dq_rs, long long dq_bs,
+                               long long dk_rs, long long dv_rs, float softmax_scale, int mask_block, void* stream) {
+    const long long st[12] = {q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs, do_rs, do_bs, dq_rs, dq_bs};
+    int rc = ag_check(head_dim, NB, H, Sq, Sk, mask_block, hstride, st, 12);
+    if (rc != VT_OK) return rc;
+    if (mask_block > 0 && (NB != 1 || Sk != Sq || dk == nullptr || dv == nullptr)) return VT_ERR_BAD_SHAPE;
+    if (mask_block == 0 && (dk32 == nullptr || dv32 == nullptr)) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o) | ((uintptr_t)dout)) & 15) return VT_ERR_BAD_ALIGN;
+    AttnGenParams p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o; p.dout = (const bf16_t*)dout;
+    p.lse2 = const_cast<float*>(lse2); p.kv_len = kv_len;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dk32 = dk32; p.dv32 = dv32;
+    p.q_rs = q_rs; p.q_bs = q_bs; p.k_rs = k_rs; p.k_bs = k_bs; p.v_rs = v_rs; p.v_bs = v_bs; p.o_rs = o_rs; p.o_bs = o_bs;
+    p.do_rs = do_rs; p.do_bs = do_bs; p.dq_rs = dq_rs; p.dq_bs = dq_bs; p.dk_rs = dk_rs; p.dv_rs = dv_rs;
+    p.NB = NB; p.H = H; p.Sq = Sq; p.Sk = Sk; p.mask_block = mask_block; p.hstride = hstride;
+    p.scale = softmax_scale; p.scale2 = softmax_scale * 1.4426950408889634f;
+    const dim3 grid((Sq + 127) / 128, H, mask_block > 0 ? 1 : NB);
+    if (head_dim == 80) hipLaunchKernelGGL(attn_gen_bwd_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_gen_bwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

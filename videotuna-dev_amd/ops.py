@@ -733,3 +733,36 @@ def attn_small_bwd(q, k, v, o, do, lse2, dq, dk, dv, H: int, scale: float, mask_
                                            q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
                                            o.stride(1), o.stride(0), do.stride(1), do.stride(0), dq.stride(1), dq.stride(0),
                                            dk.stride(1), dv.stride(1), scale, mask_block, _stream()), "vt_attn_small_bwd")
+
+
+def attn_gen_fwd(q, k, v, o, lse2, H: int, head_dim: int, hstride: int, scale: float, kv_len=None, mask_block: int = 0):
+    """head_dim 80 | 128 (csrc/attn_gen.hip).  q, o [NB, Sq, >= H*hstride]; k, v [NB, Sk, ...]; kv_len int32 [NB] | None"""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _req(t, BF16, n, 3)
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len", 1)
+    NB, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    check(load_library().vt_attn_gen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse2), _p(kv_len), head_dim, hstride,
+                                         NB, H, Sq, Sk, q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                         o.stride(1), o.stride(0), scale, mask_block, _stream()), "vt_attn_gen_fwd")
+
+
+def attn_gen_bwd(q, k, v, o, do, lse2, dq, dk, dv, H: int, head_dim: int, hstride: int, scale: float, kv_len=None, mask_block: int = 0):
+    """mask_block > 0: dk, dv bf16 like k, v; otherwise fp32 [NB, Sk, H*hstride] contiguous accumulators (zeroed here)"""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dq", dq)):
+        _req(t, BF16, n, 3)
+    NB, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    if mask_block > 0:
+        _req(dk, BF16, "dk", 3); _req(dv, BF16, "dv", 3)
+        args = (dk.data_ptr(), dv.data_ptr(), None, None)
+    else:
+        _req(dk, torch.float32, "dk", 3); _req(dv, torch.float32, "dv", 3)
+        if not (dk.is_contiguous() and dv.is_contiguous()):
+            raise ValueError("dk / dv accumulators must be contiguous")
+        dk.zero_(); dv.zero_()
+        args = (None, None, dk.data_ptr(), dv.data_ptr())
+    check(load_library().vt_attn_gen_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse2.data_ptr(), _p(kv_len),
+                                         dq.data_ptr(), *args, head_dim, hstride, NB, H, Sq, Sk,
+                                         q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                         o.stride(1), o.stride(0), do.stride(1), do.stride(0), dq.stride(1), dq.stride(0),
+                                         dk.stride(1), dv.stride(1), scale, mask_block, _stream()), "vt_attn_gen_bwd")

@@ -329,6 +329,14 @@ int vt_attn_gen_bwd(const void* q, const void* k, const void* v, const void* o, 
                     long long o_rs, long long o_bs, long long do_rs, long long do_bs, long long dq_rs, long long dq_bs,
                     long long dk_rs, long long dv_rs, float softmax_scale, int mask_block, void* stream);
 
+/* OpenSora v1.0 training loss, LatentDiffusion.p_losses (videotuna/models/opensora/models/iddpm3d.py:1332-1413) for the defaults EPSILON /
+ * LEARNED_RANGE / MSE: out fp32 [B, 2C, ...] = (eps_hat | v);  loss = mean_b( mse_b + vb_b ) with the variational-bound term of
+ * _vb_terms_bpd (:1543-1583) through OpenSoraScheduler.p_mean_variance (:444-519, whose inverted mean-type branch :497-500 is reproduced).
+ * coef fp64 [B, 8] = sqrt_ac, sqrt_1mac, posterior_mean_coef1, coef2, min_log, max_log, (t == 0), 0 at the sample's timestep; the VB
+ * arithmetic is fp64 as in the reference (float64 posterior tables).  loss3 fp64 [3] = loss, mse, vb; dout fp32 like out | NULL. */
+int vt_opensora_loss(const float* out, const float* x0, const float* noise, const double* coef, double* loss3, float* dout,
+                     long long per_channel, int C, int B, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""OpenSora STDiT on the device (vt355.stdit) against the CPU oracle (oracle/stdit_oracle.py, pinned to the imported reference STDiT and to
+the reference's loss code by tests/golden/stdit_*.npz) -- BASELINE configs[0], SURVEY 8(a) a14-a15."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _tiny(dev):
+    import stdit_oracle as SO
+    from vt355.stdit import STDiT
+    cfg = SO.tiny_config()
+    m = STDiT(input_size=cfg.input_size, in_channels=cfg.in_channels, patch_size=cfg.patch_size, hidden_size=cfg.hidden_size, depth=cfg.depth,
+              num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, class_dropout_prob=0.0, caption_channels=cfg.caption_channels,
+              model_max_length=cfg.model_max_length, space_scale=cfg.space_scale, time_scale=cfg.time_scale)
+    P = SO.init_params(cfg, seed=3)
+    assert list(P) == [k for k, _ in m.named_parameters()]
+    m.load_state_dict(P, strict=False)
+    m.to(dev)
+    Pr = {k: v.detach().float().cpu().double() for k, v in m.named_parameters()}
+    return SO, cfg, m, Pr
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_tiny_stdit_forward_matches_golden_and_oracle(dev):
+    SO, cfg, m, Pr = _tiny(dev)
+    g = np.load(os.path.join(G, "stdit_tiny.npz"))
+    x, y, mask, t = [torch.from_numpy(g[k]) for k in ("x", "y", "mask", "t")]
+    with torch.no_grad():
+        out = m(x.to(dev, BF), t.to(dev), y.to(dev, BF), mask.to(dev))
+    ref = SO.stdit_forward(Pr, cfg, x.to(BF).double(), t, y.to(BF).double(), mask)
+    e1, e2 = _rel(out, ref), _rel(out, torch.from_numpy(g["out"]))
+    print(f"[stdit tiny fwd] rel-L2 vs oracle {e1:.3e}, vs reference golden (fp32 weights) {e2:.3e}")
+    assert out.dtype == torch.float32 and e1 < 3e-2 and e2 < 5e-2
+
+
+def test_tiny_stdit_train_step_matches_oracle(dev):
+    """the reference's loss (mse + learned-variance VB term, t = 0 branch included) and every parameter gradient vs the fp64 oracle"""
+    from vt355 import ops
+    from vt355.optim import FusedAdamW
+    from vt355.stdit import OpenSoraScheduler, _OpenSoraLoss
+    SO, cfg, m, Pr = _tiny(dev)
+    ts = m.enable_training()
+    gen = torch.Generator().manual_seed(21)
+    B = 3
+    x0 = torch.randn(B, 4, *cfg.input_size, generator=gen)
+    noise = torch.randn(x0.shape, generator=gen)
+    y = torch.randn(B, 1, cfg.model_max_length, cfg.caption_channels, generator=gen).to(BF).float()
+    mask = torch.zeros(B, cfg.model_max_length, dtype=torch.int64); mask[0, :3] = 1; mask[1, :12] = 1; mask[2, :7] = 1
+    t = torch.tensor([0, 250, 999])
+    sch = OpenSoraScheduler()
+    coef = sch.coef(t.to(dev))
+    x_t = torch.empty(x0.shape, dtype=BF, device=dev)
+    ops.q_sample(x0.to(dev), noise.to(dev), coef[:, 0].float().contiguous(), coef[:, 1].float().contiguous(), None, x_t)
+    out = m(x_t, t.to(dev), y.to(dev, BF), mask.to(dev))
+    loss = _OpenSoraLoss.apply(out, x0.to(dev), noise.to(dev), coef)
+    loss.backward()
+    osch = SO.schedule(1000)
+    for v in Pr.values():
+        v.requires_grad_(True)
+    ref = SO.stdit_forward(Pr, cfg, x_t.float().cpu().double(), t, y.double(), mask)
+    # the device loss sees the model output rounded through its bf16 rows and cast to fp32, as the reference's fp32 cast does
+    lref, mse, vb = SO.opensora_loss(ref.double(), x0.double(), noise.double(), t, {k: (v.double() if v.is_floating_point() else v) for k, v in osch.items()})
+    lref.backward()
+    print(f"[stdit tiny train] loss dev {loss.item():.5f} oracle {lref.item():.5f} (mse {mse.item():.4f} vb {vb.item():.4f})")
+    assert abs(loss.item() - lref.item()) < 2e-2 * abs(lref.item())
+    worst, bad, tn, td = 0.0, [], 0.0, 0.0
+    for n in m.shapes:
+        gd = m._view(ts.grad, n).detach().double().cpu()
+        gr = Pr[n].grad
+        e, d = (gd - gr).norm().item(), gr.norm().item()
+        tn += e * e; td += d * d
+        cos = torch.nn.functional.cosine_similarity(gd.flatten(), gr.flatten(), dim=0).item()
+        if cos < 0.98 or e / max(d, 1e-12) > 0.2:
+            bad.append((n, e / max(d, 1e-12), cos))
+        worst = max(worst, e / max(d, 1e-12))
+    print(f"[stdit tiny train] grads: overall rel-L2 {(tn / td) ** 0.5:.3e}, worst per-parameter {worst:.3e}")
+    assert not bad, bad[:8]
+    opt = FusedAdamW(ts.params, lr=1e-3, fullft_state=ts)
+    before = ts.flat.clone()
+    opt.step()
+    assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
+
+
+def test_opensora_loss_kernel_matches_golden(dev):
+    """vt_opensora_loss vs the reference's own p_losses run (tests/golden/stdit_loss.npz): loss, mse / vb parts, d loss / d model output"""
+    from vt355 import ops
+    from vt355.stdit import OpenSoraScheduler
+    g = np.load(os.path.join(G, "stdit_loss.npz"))
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    coef = OpenSoraScheduler().coef(T("t"))
+    loss3 = torch.empty(3, dtype=torch.float64, device=dev)
+    dout = torch.empty(g["model_out"].shape, device=dev)
+    ops.opensora_loss(T("model_out"), T("x0"), T("noise"), coef, loss3, dout)
+    l = loss3.cpu()
+    assert abs(l[0].item() - float(g["loss"])) < 1e-6 * float(g["loss"])
+    assert abs(l[1].item() - float(g["loss_mse"])) < 1e-5 * float(g["loss_mse"]) and abs(l[2].item() - float(g["loss_vb"])) < 1e-6 * float(g["loss_vb"])
+    r = torch.from_numpy(g["dmodel_out"])
+    assert (dout.cpu() - r).abs().max().item() < 1e-4 * r.abs().max().item()

@@ -24,6 +24,11 @@ TARGET_REMAP = {
     "videotuna.models.lvdm.ddpm3d.LVDMFlow": "vt355.lvdm.LVDMFlow",
     "videotuna.schedulers.ddpm.LDDPM": "vt355.lvdm.LDDPM",
     "videotuna.schedulers.diffusion_schedulers.LDMScheduler": "vt355.lvdm.LDMScheduler",
+    # OpenSora v1.0 (configs/003_opensora/opensorav10_256x256.yaml)
+    "videotuna.models.opensora.models.stdit.stdit.STDiT_XL_2": "vt355.stdit.STDiT_XL_2",
+    "videotuna.models.opensora.models.stdit.stdit.STDiT": "vt355.stdit.STDiT",
+    "videotuna.models.opensora.models.iddpm3d.LatentDiffusion": "vt355.stdit.OpenSoraFlow",
+    "videotuna.models.opensora.models.iddpm3d.OpenSoraScheduler": "vt355.stdit.OpenSoraScheduler",
 }
 _NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
 

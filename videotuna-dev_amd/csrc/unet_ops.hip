@@ -343,3 +343,85 @@ extern "C" int vt_mse_loss(const void* pred, const float* target, float* loss, v
                        1.0f / (float)total, grad_scale);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
+
+// ----------------------------------------------------------------------------------------------------------------- OpenSora IDDPM loss
+// LatentDiffusion.p_losses of OpenSora v1.0 (videotuna/models/opensora/models/iddpm3d.py:1332-1413; EPSILON mean, LEARNED_RANGE variance,
+// MSE loss): model output [B, 2C, ...] = (eps_hat | v);  loss = mean_b( mean (eps - eps_hat)^2 + vb_b ),
+//   vb_b = KL( q(x_{t-1} | x_t, x0) || N(mean_p, exp(lv)) ) / ln 2   (t > 0)   |   -log-likelihood of the discretised Gaussian / ln 2 (t == 0)
+//   lv = frac * max_log + (1 - frac) * min_log, frac = (v + 1) / 2;  mean_p = coef1 * eps_hat + coef2 * x_t  -- the reference feeds the RAW
+//   eps_hat where x0 is expected (OpenSoraScheduler.p_mean_variance :497-500, a quirk reproduced on purpose); the mean prediction is
+//   detached inside vb (:1366), so d vb flows to v only.
+// coef: fp64 [B, 8] = sqrt_ac, sqrt_1mac, coef1, coef2, min_log, max_log, (t == 0), unused -- the reference's posterior tables are
+// float64 (np.append(1.0, ...)), so the VB arithmetic runs in fp64 here as it (implicitly) does there.
+// out: fp32 in (model output cast to fp32, stdit.py:309); x0, noise fp32; loss3: fp64 [3] = loss, mse, vb (zeroed by the call);
+// dout fp32 [B, 2C, ...] = d loss / d out * gscale.
+__device__ __forceinline__ double os_cdf(double x) { return 0.5 * (1.0 + tanh(0.7978845608028654 * (x + 0.044715 * x * x * x))); }
+__device__ __forceinline__ double os_dcdf(double x) {
+    const double u = 0.7978845608028654 * (x + 0.044715 * x * x * x);
+    const double th = tanh(u);
+    return 0.5 * (1.0 - th * th) * 0.7978845608028654 * (1.0 + 3.0 * 0.044715 * x * x);
+}
+__global__ __launch_bounds__(UO_THREADS) void opensora_loss_kernel(const float* out, const float* x0, const float* noise, const double* coef,
+                                                                  double* loss3, float* dout, long long per_c, int C, int B, float gscale) {
+    // per_c = elements per channel group (T*H*W); sample b: eps_hat at [b, 0:C], v at [b, C:2C]
+    const long long per = per_c * C, total = per * B;
+    double a_mse = 0.0, a_vb = 0.0;
+    const double inv = 1.0 / ((double)per * (double)B);
+    const double LN2 = 0.6931471805599453;
+    for (long long i = (long long)blockIdx.x * UO_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * UO_THREADS) {
+        const int b = (int)(i / per);
+        const long long r = i - (long long)b * per;
+        const double* cf = coef + b * 8;
+        const long long ie = (long long)b * 2 * per + r, iv = ie + per;
+        const double e = out[ie], v = out[iv], xs = x0[i], nz = noise[i];
+        const double xt = cf[0] * xs + cf[1] * nz;
+        const double d = nz - e;
+        a_mse += d * d;
+        const double frac = 0.5 * (v + 1.0);
+        const double lv = frac * cf[5] + (1.0 - frac) * cf[4];
+        const double mp = cf[2] * e + cf[3] * xt;                // REFERENCE QUIRK: raw eps_hat in the place of x0
+        double term, dlv;
+        if (cf[6] == 0.0) {
+            const double mt = cf[2] * xs + cf[3] * xt, lt = cf[4];
+            const double dm2 = (mt - mp) * (mt - mp), ex = exp(lt - lv), ev = exp(-lv);
+            term = 0.5 * (-1.0 + lv - lt + ex + dm2 * ev);
+            dlv = 0.5 * (1.0 - ex - dm2 * ev);
+        } else {
+            const double ls = 0.5 * lv, is = exp(-ls), c = xs - mp;
+            const double zp = is * (c + 1.0 / 255.0), zm = is * (c - 1.0 / 255.0);
+            const double cp = os_cdf(zp), cm = os_cdf(zm);
+            double ll, dls;           // d z / d ls = -z
+            if (xs < -0.999) { const double q = cp > 1e-12 ? cp : 1e-12; ll = log(q); dls = cp > 1e-12 ? os_dcdf(zp) * (-zp) / q : 0.0; }
+            else if (xs > 0.999) { const double q = (1.0 - cm) > 1e-12 ? (1.0 - cm) : 1e-12; ll = log(q); dls = (1.0 - cm) > 1e-12 ? -os_dcdf(zm) * (-zm) / q : 0.0; }
+            else { const double dl = cp - cm; const double q = dl > 1e-12 ? dl : 1e-12; ll = log(q); dls = dl > 1e-12 ? (os_dcdf(zp) * (-zp) - os_dcdf(zm) * (-zm)) / q : 0.0; }
+            term = -ll;
+            dlv = -0.5 * dls;
+        }
+        a_vb += term;
+        if (dout != nullptr) {
+            dout[ie] = (float)(-2.0 * d * inv * gscale);
+            dout[iv] = (float)(dlv * 0.5 * (cf[5] - cf[4]) / LN2 * inv * gscale);
+        }
+    }
+    __shared__ double red[2][UO_THREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a_mse += __shfl_xor(a_mse, o, 64); a_vb += __shfl_xor(a_vb, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a_mse; red[1][threadIdx.x >> 6] = a_vb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0.0, v = 0.0;
+        for (int i = 0; i < UO_THREADS / 64; ++i) { m += red[0][i]; v += red[1][i]; }
+        m *= inv; v *= inv / LN2;
+        atomicAdd(loss3 + 1, m); atomicAdd(loss3 + 2, v); atomicAdd(loss3, m + v);
+    }
+}
+extern "C" int vt_opensora_loss(const float* out, const float* x0, const float* noise, const double* coef, double* loss3, float* dout,
+                                long long per_channel, int C, int B, float grad_scale, void* stream) {
+    if (per_channel <= 0 || C <= 0 || B <= 0) return VT_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss3, 0, 24, st) != hipSuccess) return VT_ERR_LAUNCH;
+    long long b = (per_channel * C * B + UO_THREADS - 1) / UO_THREADS;
+    hipLaunchKernelGGL(opensora_loss_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(UO_THREADS), 0, st, out, x0, noise, coef, loss3, dout,
+                       per_channel, C, B, grad_scale);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

@@ -766,3 +766,14 @@ def attn_gen_bwd(q, k, v, o, do, lse2, dq, dk, dv, H: int, head_dim: int, hstrid
                                          q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
                                          o.stride(1), o.stride(0), do.stride(1), do.stride(0), dq.stride(1), dq.stride(0),
                                          dk.stride(1), dv.stride(1), scale, mask_block, _stream()), "vt_attn_gen_bwd")
+
+
+def opensora_loss(out, x0, noise, coef, loss3, dout=None, grad_scale: float = 1.0):
+    """out fp32 [B, 2C, ...], x0 / noise fp32 [B, C, ...], coef fp64 [B, 8], loss3 fp64 [3] (loss, mse, vb), dout fp32 like out | None"""
+    _req(out, torch.float32, "out"); _req(x0, torch.float32, "x0"); _req(noise, torch.float32, "noise")
+    _req(coef, torch.float64, "coef", 2); _req(loss3, torch.float64, "loss3", 1)
+    B, C = x0.shape[0], x0.shape[1]
+    if out.shape[1] != 2 * C or not (out.is_contiguous() and x0.is_contiguous() and noise.is_contiguous()):
+        raise ValueError("out must be contiguous [B, 2C, ...] next to contiguous x0 / noise [B, C, ...]")
+    check(load_library().vt_opensora_loss(out.data_ptr(), x0.data_ptr(), noise.data_ptr(), coef.data_ptr(), loss3.data_ptr(), _p(dout),
+                                          x0.numel() // (B * C), C, B, grad_scale, _stream()), "vt_opensora_loss")

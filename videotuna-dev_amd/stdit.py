@@ -1,0 +1,602 @@
+"""OpenSora v1.0 on the vt355 kernels: ``STDiT`` with the constructor keys, parameter names and ``forward`` signature of
+videotuna/models/opensora/models/stdit/stdit.py:136-416 (``STDiT_XL_2`` :419-426) and the training loss of
+``LatentDiffusion.p_losses`` (models/iddpm3d.py:1332-1413) -- BASELINE configs[0], SURVEY 8(a) a14-a15.
+
+Rows = tokens [B*T*S, D] in the reference's (t, s) order, bf16.  Per STDiTBlock (stdit.py:102-132): LayerNorm(no affine) + t2i_modulate in
+one kernel (vt_ln_modulate), spatial attention over [B*T] sequences of S tokens and temporal attention over [B*S] sequences of T frames
+(one row transpose each way) through vt_attn_gen (16 heads x 72, stored 80 wide: the q/k/v/proj weights are packed with 8 zero rows /
+columns per head once per optimizer step), both gated by gate_msa as the reference does, the varlen text cross-attention through the same
+kernel with per-sample key lengths (no packing of the text tokens), GELU-tanh MLP in the GEMM epilogues, gated residuals in the GEMM
+epilogues.  Training = full fine-tune through the tape of vt355.unet (FlatParamModule / _Run); class_dropout_prob is not applied (the
+reference's token_drop is CUDA-only code).  No CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_GATED_RES
+from .unet import F32, FlatParamModule, _Run, _Var
+
+HP = 80            # stored head width: 72 real + 8 zero (five 16-wide MFMA k-steps)
+
+
+def _shapes(c) -> Dict[str, tuple]:
+    D, H4 = c.hidden_size, int(c.hidden_size * c.mlp_ratio)
+    sh = {"x_embedder.proj.weight": (D, c.in_channels) + tuple(c.patch_size), "x_embedder.proj.bias": (D,),
+          "t_embedder.mlp.0.weight": (D, 256), "t_embedder.mlp.0.bias": (D,), "t_embedder.mlp.2.weight": (D, D), "t_embedder.mlp.2.bias": (D,),
+          "t_block.1.weight": (6 * D, D), "t_block.1.bias": (6 * D,),
+          "y_embedder.y_proj.fc1.weight": (D, c.caption_channels), "y_embedder.y_proj.fc1.bias": (D,),
+          "y_embedder.y_proj.fc2.weight": (D, D), "y_embedder.y_proj.fc2.bias": (D,)}
+    for i in range(c.depth):
+        b = f"blocks.{i}."
+        sh[b + "scale_shift_table"] = (6, D)
+        sh[b + "attn.qkv.weight"] = (3 * D, D); sh[b + "attn.qkv.bias"] = (3 * D,)
+        sh[b + "attn.proj.weight"] = (D, D); sh[b + "attn.proj.bias"] = (D,)
+        sh[b + "cross_attn.q_linear.weight"] = (D, D); sh[b + "cross_attn.q_linear.bias"] = (D,)
+        sh[b + "cross_attn.kv_linear.weight"] = (2 * D, D); sh[b + "cross_attn.kv_linear.bias"] = (2 * D,)
+        sh[b + "cross_attn.proj.weight"] = (D, D); sh[b + "cross_attn.proj.bias"] = (D,)
+        sh[b + "mlp.fc1.weight"] = (H4, D); sh[b + "mlp.fc1.bias"] = (H4,)
+        sh[b + "mlp.fc2.weight"] = (D, H4); sh[b + "mlp.fc2.bias"] = (D,)
+        sh[b + "attn_temp.qkv.weight"] = (3 * D, D); sh[b + "attn_temp.qkv.bias"] = (3 * D,)
+        sh[b + "attn_temp.proj.weight"] = (D, D); sh[b + "attn_temp.proj.bias"] = (D,)
+    sh["final_layer.scale_shift_table"] = (2, D)
+    sh["final_layer.linear.weight"] = (math.prod(c.patch_size) * 2 * c.in_channels, D)
+    sh["final_layer.linear.bias"] = (math.prod(c.patch_size) * 2 * c.in_channels,)
+    return sh
+
+
+def _sincos_1d(dim, pos):
+    omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+class STDiT(FlatParamModule):
+    def __init__(self, input_size=(1, 32, 32), in_channels=4, patch_size=(1, 2, 2), hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4.0,
+                 class_dropout_prob=0.1, pred_sigma=True, drop_path=0.0, no_temporal_pos_emb=False, caption_channels=4096,
+                 model_max_length=120, dtype=torch.bfloat16, space_scale=1.0, time_scale=1.0, freeze=None, enable_flashattn=False,
+                 enable_layernorm_kernel=False, enable_sequence_parallelism=False, from_pretrained=None):
+        super().__init__()
+        bad = [k for k, v in dict(drop_path=drop_path != 0.0, no_temporal_pos_emb=no_temporal_pos_emb, freeze=freeze is not None,
+                                  sequence_parallelism=enable_sequence_parallelism, not_pred_sigma=not pred_sigma,
+                                  from_pretrained=bool(from_pretrained), patch_t=patch_size[0] != 1).items() if v]
+        if bad:
+            raise NotImplementedError(f"vt355 STDiT implements the configs/003_opensora recipe; unsupported options: {bad}")
+        if hidden_size % 64 or hidden_size // num_heads != 72 or caption_channels % 64:
+            raise ValueError("hidden_size must be a multiple of 64 with 72-wide heads (STDiT-XL/2: 1152 = 16 x 72); caption_channels % 64 == 0")
+        T = input_size[0] // patch_size[0]
+        if 32 % T:
+            raise ValueError("the number of frames must divide 32 (packed temporal attention)")
+        self.config = SimpleNamespace(input_size=tuple(input_size), in_channels=in_channels, patch_size=tuple(patch_size), hidden_size=hidden_size,
+                                      depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, caption_channels=caption_channels,
+                                      model_max_length=model_max_length, space_scale=space_scale, time_scale=time_scale,
+                                      class_dropout_prob=class_dropout_prob)
+        self.in_channels, self.out_channels = in_channels, 2 * in_channels
+        self.hidden_size, self.num_heads, self.depth = hidden_size, num_heads, depth
+        self.num_temporal = T
+        self.num_spatial = (input_size[1] // patch_size[1]) * (input_size[2] // patch_size[2])
+        self._setup_flat(_shapes(self.config))
+        gh, gw = input_size[1] // patch_size[1], input_size[2] // patch_size[2]
+        grid = np.stack(np.meshgrid(np.arange(gw, dtype=np.float32) / space_scale, np.arange(gh, dtype=np.float32) / space_scale), axis=0)
+        grid = grid.reshape([2, 1, gw, gh])
+        pe = np.concatenate([_sincos_1d(hidden_size // 2, grid[0]), _sincos_1d(hidden_size // 2, grid[1])], axis=1)
+        self.register_buffer("pos_embed", torch.from_numpy(pe).float().unsqueeze(0))                       # blocks.py:857-919
+        self.register_buffer("pos_embed_temporal", torch.from_numpy(_sincos_1d(hidden_size, np.arange(T)[..., None] / time_scale)).float().unsqueeze(0))
+        self.y_embedder.register_buffer("y_embedding", torch.randn(model_max_length, caption_channels) / caption_channels ** 0.5)
+
+    def init_weights(self, seed: int = 0):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for n, p in self._plist.items():
+                s = self.shapes[n]
+                if n.endswith("scale_shift_table"):
+                    w = torch.randn(s, generator=g) / s[1] ** 0.5
+                elif len(s) == 1:
+                    w = torch.randn(s, generator=g) * 0.05
+                else:
+                    w = torch.randn(s, generator=g) * (0.8 / math.sqrt(math.prod(s[1:])))
+                p.copy_(w.to(p.device, BF16))
+        self._packed = None
+        return self
+
+    def forward(self, x, timestep, y, mask=None):
+        """x [B, C, T, H, W], timestep [B], y [B, 1, L, caption_channels], mask [B, L] -> fp32 [B, 2C, T, H, W] (stdit.py:236-311)"""
+        if not x.is_cuda:
+            raise RuntimeError("vt355 STDiT runs only on an MI355X device (no CPU fallback)")
+        need_grad = torch.is_grad_enabled() and self.train_state is not None
+        if need_grad:
+            anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            return _STFn.apply(anchor, self, x, timestep, y, mask)
+        return _STRun(self, save=False).forward(x, timestep, y, mask)
+
+
+def STDiT_XL_2(from_pretrained=None, **kwargs):
+    return STDiT(depth=28, hidden_size=1152, patch_size=(1, 2, 2), num_heads=16, from_pretrained=from_pretrained, **kwargs)
+
+
+class _STFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x, t, y, mask):
+        run = _STRun(model, save=True)
+        out = run.forward(x, t, y, mask)
+        ctx.run = run
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.run.backward(dout)
+        ctx.run = None
+        return None, None, None, None, None, None
+
+
+def _pad_heads_rows(w, groups, H):
+    """[groups*H*72, K] -> [groups*H*80, K] (zero rows); 1-d biases alike"""
+    if w.dim() == 1:
+        out = torch.zeros(groups, H, HP, dtype=w.dtype, device=w.device)
+        out[..., :72] = w.view(groups, H, 72)
+        return out.view(-1)
+    out = torch.zeros(groups, H, HP, w.shape[1], dtype=w.dtype, device=w.device)
+    out[:, :, :72] = w.view(groups, H, 72, w.shape[1])
+    return out.view(-1, w.shape[1])
+
+
+def _pad_heads_cols(w, H):
+    """[N, H*72] -> [N, H*80] (zero columns)"""
+    out = torch.zeros(w.shape[0], H, HP, dtype=w.dtype, device=w.device)
+    out[..., :72] = w.view(w.shape[0], H, 72)
+    return out.view(w.shape[0], -1)
+
+
+def _packed_stdit(model: STDiT) -> SimpleNamespace:
+    ver = -1 if model.train_state is None else model.train_state.version
+    if model._packed is not None and model._packed_version == ver:
+        return model._packed
+    P = SimpleNamespace(wt={}, w={}, b={})
+    fb = model.flat_bf16
+    H = model.num_heads
+    train = model.train_state is not None
+    with torch.no_grad():
+        for n, shp in model.shapes.items():
+            if not n.endswith(".weight") or len(shp) < 2:
+                continue
+            w = model.flat(fb, n)
+            bn = n[:-6] + "bias"
+            if n.endswith(("attn.qkv.weight", "attn_temp.qkv.weight")):
+                P.w[n] = _pad_heads_rows(w, 3, H); P.b[n] = _pad_heads_rows(model.flat(fb, bn), 3, H)
+            elif n.endswith("cross_attn.q_linear.weight"):
+                P.w[n] = _pad_heads_rows(w, 1, H); P.b[n] = _pad_heads_rows(model.flat(fb, bn), 1, H)
+            elif n.endswith("cross_attn.kv_linear.weight"):
+                P.w[n] = _pad_heads_rows(w, 2, H); P.b[n] = _pad_heads_rows(model.flat(fb, bn), 2, H)
+            elif n.endswith(("attn.proj.weight", "attn_temp.proj.weight", "cross_attn.proj.weight")):
+                P.w[n] = _pad_heads_cols(w, H)
+            elif n == "x_embedder.proj.weight":
+                wp = torch.zeros(w.shape[0], 64, dtype=BF16, device=w.device)          # K = C*pt*ph*pw (16) padded to one K-tile
+                wp[:, :w.shape[1]] = w
+                P.w[n] = wp
+            if train and n != "x_embedder.proj.weight":
+                P.wt[n] = (P.w[n] if n in P.w else w).t().contiguous()
+    model._packed, model._packed_version = P, ver
+    return P
+
+
+class _STRun(_Run):
+    def __init__(self, model: STDiT, save: bool):
+        self.m, self.save = model, save
+        self.c = model.config
+        self.P = _packed_stdit(model)
+        self.fb = model.flat_bf16
+        self.ts = model.train_state
+        self.tape = []
+        self.dev = model.device
+
+    # a Linear whose kernel operand is a packed copy of the parameter (padded heads): forward / dX through the copy, the parameter
+    # gradients are gathered back from the padded gradient
+    def plinear(self, x: _Var, wname: str, kind: str, groups: int = 1, residual: Optional[_Var] = None, gate=None, dgate=None) -> _Var:
+        """kind "rows": output features padded per head (qkv / q / kv projections, with bias); "cols": input features padded (proj).
+        residual: y = residual + [gate[b] *] (x W^T + b); gate = (fp32 [B, D] view, batch stride, rows per sample), dgate receives (+=)
+        sum_rows dy * branch"""
+        H = self.m.num_heads
+        bname = wname[:-6] + "bias"
+        w = self.P.w[wname]
+        b = self.P.b[wname] if kind == "rows" else self.W(bname)
+        M = x.d.shape[0]
+        y = self.E(M, w.shape[0])
+        branch = self.E(M, w.shape[0]) if (self.save and gate is not None) else None
+        if residual is not None:
+            g = (gate[0], gate[0], gate[1], gate[2]) if gate is not None else (None, None, 0, 1)
+            ops.gemm(x.d, w, y, b, epilogue=EPI_GATED_RES, residual=residual.d, gate_txt=g[0], gate_vid=g[1], gate_bstride=g[2], S=g[3], St=0,
+                     pre_act_out=branch)
+        else:
+            ops.gemm(x.d, w, y, b)
+        yv = _Var(y)
+        if self.save:
+            def bwd_plinear():
+                g_ = yv.g
+                if residual is not None:
+                    self.acc(residual, g_)
+                if gate is not None:
+                    ops.group_colsum(g_, None, y=branch, out2=dgate, D=w.shape[0], S=gate[2], St=0, grouped=True, o_bstride=gate[1], o_segstride=0)
+                    gg = self.E(M, w.shape[0])
+                    ops.gate_mul(g_, gg, gate[0], gate[0], gate[1], w.shape[0], gate[2], 0)
+                    g_ = gg
+                dwp = torch.zeros(w.shape, dtype=F32, device=self.dev)
+                ops.linear_dw(g_, x.d, dwp, accumulate=False)
+                dw = self.G(wname)
+                if kind == "rows":
+                    dw.view(groups, H, 72, -1).add_(dwp.view(groups, H, HP, -1)[:, :, :72])
+                    dbp = torch.zeros(w.shape[0], dtype=F32, device=self.dev)
+                    ops.group_colsum(g_, dbp, D=w.shape[0])
+                    self.G(bname).view(groups, H, 72).add_(dbp.view(groups, H, HP)[..., :72])
+                else:
+                    dw.view(dw.shape[0], H, 72).add_(dwp.view(dw.shape[0], H, HP)[..., :72])
+                    ops.group_colsum(g_, self.G(bname), D=w.shape[0])
+                if x.g is not False:
+                    dx = self.E(M, w.shape[1])
+                    ops.gemm(g_, self.P.wt[wname], dx, None)
+                    self.acc(x, dx)
+            self.tape.append(bwd_plinear)
+        return yv
+
+    def mlp(self, x: _Var, pre: str, residual: Optional[_Var] = None, gate=None, dgate=None) -> _Var:
+        """Mlp(fc1 -> GELU(tanh) -> fc2) [+ gated residual]; GELU and its derivative live in the GEMM epilogues"""
+        M = x.d.shape[0]
+        w1, w2 = self.W(pre + "fc1.weight"), self.W(pre + "fc2.weight")
+        H4, Dout = w1.shape[0], w2.shape[0]
+        u = self.E(M, H4); ga = self.E(M, H4)
+        ops.gemm(x.d, w1, ga, self.W(pre + "fc1.bias"), epilogue=EPI_BIAS_GELU, pre_act_out=u)
+        y = self.E(M, Dout)
+        branch = self.E(M, Dout) if (self.save and gate is not None) else None
+        if residual is not None:
+            g = (gate[0], gate[0], gate[1], gate[2]) if gate is not None else (None, None, 0, 1)
+            ops.gemm(ga, w2, y, self.W(pre + "fc2.bias"), epilogue=EPI_GATED_RES, residual=residual.d, gate_txt=g[0], gate_vid=g[1],
+                     gate_bstride=g[2], S=g[3], St=0, pre_act_out=branch)
+        else:
+            ops.gemm(ga, w2, y, self.W(pre + "fc2.bias"))
+        yv = _Var(y)
+        if self.save:
+            def bwd_mlp():
+                g_ = yv.g
+                if residual is not None:
+                    self.acc(residual, g_)
+                if gate is not None:
+                    ops.group_colsum(g_, None, y=branch, out2=dgate, D=Dout, S=gate[2], St=0, grouped=True, o_bstride=gate[1], o_segstride=0)
+                    gg = self.E(M, Dout)
+                    ops.gate_mul(g_, gg, gate[0], gate[0], gate[1], Dout, gate[2], 0)
+                    g_ = gg
+                ops.group_colsum(g_, self.G(pre + "fc2.bias"), D=Dout)
+                self.dW(g_, ga, self.G(pre + "fc2.weight"))
+                du = self.E(M, H4)
+                ops.gemm(g_, self.P.wt[pre + "fc2.weight"], du, None, epilogue=EPI_DGELU, pre_act_in=u)      # (g W2) * gelu'(u)
+                ops.group_colsum(du, self.G(pre + "fc1.bias"), D=H4)
+                self.dW(du, x.d, self.G(pre + "fc1.weight"))
+                if x.g is not False:
+                    dx = self.E(M, w1.shape[1])
+                    ops.gemm(du, self.P.wt[pre + "fc1.weight"], dx, None)
+                    self.acc(x, dx)
+            self.tape.append(bwd_mlp)
+        return yv
+
+    def ln_mod(self, x: _Var, shift, scale, bstride: int, rows_per_sample: int, dshift, dscale, dbstride: int) -> _Var:
+        """t2i_modulate(LayerNorm(x), shift, scale) (blocks.py:75-76, no affine, eps 1e-6); shift / scale fp32 [B, D] views with batch stride
+        bstride; dshift / dscale: fp32 [B, D] views that receive (+=) their gradients"""
+        M, D = x.d.shape
+        y = self.E(M, D)
+        mean, rstd = self.E(M, dt=F32), self.E(M, dt=F32)
+        ops.ln_modulate_fwd(x.d, y, None, None, (shift, scale, shift, scale, bstride), mean, rstd, D, rows_per_sample, 0, 1e-6)
+        yv = _Var(y)
+        if self.save:
+            def bwd_ln_mod():
+                g = yv.g
+                # d shift[b] = sum_rows g ; d scale[b] = sum_rows g * xhat
+                ops.group_colsum(g, dshift, y=x.d, out2=dscale, mean=mean, rstd=rstd, D=D, S=rows_per_sample, St=0, grouped=True,
+                                 o_bstride=dbstride, o_segstride=0)
+                dx = self.E(M, D)
+                ops.ln_modulate_bwd(g, x.d, mean, rstd, None, (scale, scale, bstride), x.g, dx, D, rows_per_sample, 0)
+                x.g = dx
+            self.tape.append(bwd_ln_mod)
+        return yv
+
+    def attention(self, qkv: _Var, nseq_or_T, mode: str, kv: Optional[_Var] = None, kv_len=None, L: int = 0) -> _Var:
+        """mode "spatial": qkv rows are nseq sequences; "packed": consecutive sequences of T rows; "cross": q rows of B samples vs kv [B*L]"""
+        H = self.m.num_heads
+        C = H * HP
+        M = qkv.d.shape[0]
+        scale = 72 ** -0.5
+        o = self.E(M, C)
+        if mode == "cross":
+            B = nseq_or_T
+            q3 = qkv.d.view(B, M // B, C)
+            kv3 = kv.d.view(B, L, 2 * C)
+            lse = self.E(B, H, M // B, dt=F32)
+            ops.attn_gen_fwd(q3, kv3[:, :, :C], kv3[:, :, C:], o.view(B, M // B, C), lse, H, HP, HP, scale, kv_len=kv_len)
+        elif mode == "spatial":
+            n = nseq_or_T
+            q3 = qkv.d.view(n, M // n, 3 * C)
+            lse = self.E(n, H, M // n, dt=F32)
+            ops.attn_gen_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(n, M // n, C), lse, H, HP, HP, scale)
+        else:
+            q3 = qkv.d.view(1, M, 3 * C)
+            lse = self.E(1, H, M, dt=F32)
+            ops.attn_gen_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(1, M, C), lse, H, HP, HP, scale, mask_block=nseq_or_T)
+        ov = _Var(o)
+        if self.save:
+            def bwd_attention():
+                g = ov.g
+                if mode == "cross":
+                    B = nseq_or_T
+                    dq = self.E(M, C)
+                    dk = self.E(B, L, C, dt=F32); dv = self.E(B, L, C, dt=F32)
+                    ops.attn_gen_bwd(q3, kv3[:, :, :C], kv3[:, :, C:], o.view(B, M // B, C), g.view(B, M // B, C), lse, dq.view(B, M // B, C),
+                                     dk, dv, H, HP, HP, scale, kv_len=kv_len)
+                    qkv.g = dq
+                    dkv = self.E(B * L, 2 * C)
+                    ops.residual_cast(dk.view(B * L, C), None, dkv[:, :C]); ops.residual_cast(dv.view(B * L, C), None, dkv[:, C:])
+                    self.acc(kv, dkv)
+                elif mode == "spatial":
+                    n = nseq_or_T
+                    dqkv = self.E(M, 3 * C)
+                    dk = self.E(n, M // n, C, dt=F32); dv = self.E(n, M // n, C, dt=F32)
+                    d3 = dqkv.view(n, M // n, 3 * C)
+                    ops.attn_gen_bwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(n, M // n, C), g.view(n, M // n, C), lse,
+                                     d3[:, :, :C], dk, dv, H, HP, HP, scale)
+                    ops.residual_cast(dk.view(M, C), None, dqkv[:, C:2 * C]); ops.residual_cast(dv.view(M, C), None, dqkv[:, 2 * C:])
+                    qkv.g = dqkv
+                else:
+                    dqkv = self.E(M, 3 * C)
+                    d3 = dqkv.view(1, M, 3 * C)
+                    ops.attn_gen_bwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], o.view(1, M, C), g.view(1, M, C), lse,
+                                     d3[:, :, :C], d3[:, :, C:2 * C], d3[:, :, 2 * C:], H, HP, HP, scale, mask_block=nseq_or_T)
+                    qkv.g = dqkv
+            self.tape.append(bwd_attention)
+        return ov
+
+    # ---- whole network ----
+    def forward(self, x, timestep, y, mask):
+        c, m = self.c, self.m
+        dev = self.dev
+        B, Cin, Tf, Hh, Ww = x.shape
+        D, H = m.hidden_size, m.num_heads
+        pt, ph, pw = c.patch_size
+        T, S = m.num_temporal, m.num_spatial
+        M = B * T * S
+        rps = T * S
+        te = D
+        # ---- patch embedding (Conv3d kernel = stride = patch, blocks.py:109-136) as a GEMM over (c, pt, ph, pw) patches + spatial sincos table ----
+        pat = torch.zeros(M, 64, dtype=BF16, device=dev)
+        pat[:, :Cin * pt * ph * pw] = x.to(BF16).view(B, Cin, T, pt, Hh // ph, ph, Ww // pw, pw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(M, -1)      # (pt ph pw c): the weight's channels-last storage
+        pos = m.pos_embed[0].to(dev, BF16).contiguous()
+        h0 = self.E(M, D)
+        ops.gemm(pat, self.P.w["x_embedder.proj.weight"], h0, self.W("x_embedder.proj.bias"), epilogue=EPI_GATED_RES, residual=pos, r_mod=S)
+        h = _Var(h0)
+        if self.save:
+            def bwd_patch():
+                dwp = torch.zeros(D, 64, dtype=F32, device=dev)
+                ops.linear_dw(h.g, pat, dwp, accumulate=False)
+                self.G("x_embedder.proj.weight").add_(dwp[:, :Cin * pt * ph * pw])
+                ops.group_colsum(h.g, self.G("x_embedder.proj.bias"), D=D)
+            self.tape.append(bwd_patch)
+        # ---- timestep: sinusoid(256) -> Linear -> SiLU -> Linear = t ; t0 = t_block(SiLU(t)) [B, 6D] ----
+        sin = self.E(B, 256); ops.timestep_embedding(timestep.to(torch.int64).contiguous(), sin, True, 0.0)
+        l0 = self.E(B, D); ops.gemm(sin, self.W("t_embedder.mlp.0.weight"), l0, self.W("t_embedder.mlp.0.bias"))
+        a0 = self.E(B, D); ops.silu(l0, a0)
+        t = self.E(B, D); ops.gemm(a0, self.W("t_embedder.mlp.2.weight"), t, self.W("t_embedder.mlp.2.bias"))
+        st = self.E(B, D); ops.silu(t, st)
+        t0 = self.E(B, 6 * D, dt=F32); ops.gemm(st, self.W("t_block.1.weight"), t0, self.W("t_block.1.bias"))
+        tf32 = t.float()
+        dt0 = torch.zeros(B, 6 * D, dtype=F32, device=dev) if self.save else None
+        dt_final = torch.zeros(B, 2 * D, dtype=F32, device=dev) if self.save else None
+        if self.save:
+            def bwd_time():
+                # t feeds t_block (through SiLU) and the final layer's table directly (T2IFinalLayer.forward, blocks.py:612)
+                dst = torch.zeros(B, D, dtype=F32, device=dev)
+                ops.small_linear_bwd(dt0, st, self.W("t_block.1.weight"), self.G("t_block.1.weight"), self.G("t_block.1.bias"), dst)
+                dt_ = torch.zeros(B, D, dtype=F32, device=dev)
+                ops.silu_bwd(dst, t, dt_)
+                dt_.add_(dt_final[:, :D]).add_(dt_final[:, D:])
+                da0 = torch.zeros(B, D, dtype=F32, device=dev)
+                ops.small_linear_bwd(dt_, a0, self.W("t_embedder.mlp.2.weight"), self.G("t_embedder.mlp.2.weight"), self.G("t_embedder.mlp.2.bias"), da0)
+                dl0 = torch.zeros(B, D, dtype=F32, device=dev)
+                ops.silu_bwd(da0, l0, dl0)
+                ops.small_linear_bwd(dl0, sin, self.W("t_embedder.mlp.0.weight"), self.G("t_embedder.mlp.0.weight"), self.G("t_embedder.mlp.0.bias"), None)
+            self.tape.append(bwd_time)
+        # ---- caption: Mlp(GELU-tanh) over all B*L text rows; masked tokens are simply never attended (per-sample key lengths) ----
+        L = y.shape[2]
+        yrows = y.to(BF16).reshape(B * L, -1).contiguous()
+        yv = _Var(yrows); yv.g = False
+        ye = self.mlp(yv, "y_embedder.y_proj.")
+        if mask is not None:
+            kv_len = mask.reshape(B, -1).sum(dim=1).to(torch.int32).contiguous()
+        else:
+            kv_len = None
+        tpe_rows = m.pos_embed_temporal[0].to(dev, BF16).repeat(B * S, 1).contiguous()          # row (b, s, t) -> tpe[t]
+
+        for i in range(c.depth):
+            pre = f"blocks.{i}."
+            mod = (self.W(pre + "scale_shift_table").float().view(1, 6 * D) + t0).contiguous()             # [B, 6D] fp32 (tiny)
+            dmod = torch.zeros(B, 6 * D, dtype=F32, device=dev) if self.save else None
+            sl = lambda k, buf=mod: buf[:, k * D:(k + 1) * D]
+            dsl = (lambda k, buf=dmod: buf[:, k * D:(k + 1) * D]) if self.save else (lambda k: None)
+            bs = 6 * D
+            x_in = h
+            if self.save:
+                def bwd_mod(pre=pre, dmod=dmod):
+                    self.G(pre + "scale_shift_table").view(-1).add_(dmod.sum(0))
+                    dt0.add_(dmod)
+                self.tape.append(bwd_mod)
+            xm = self.ln_mod(x_in, sl(0), sl(1), bs, rps, dsl(0), dsl(1), bs)
+            # spatial attention, gated
+            qkv = self.plinear(xm, pre + "attn.qkv.weight", "rows", 3)
+            ao = self.attention(qkv, B * T, "spatial")
+            x1 = self.plinear(ao, pre + "attn.proj.weight", "cols", residual=x_in, gate=(sl(2), bs, rps), dgate=dsl(2))
+            # temporal attention (pixel-major rows), gated with the SAME gate_msa (stdit.py:114,122)
+            xt = self.E(M, D); ops.row_map(x1.d, xt, 0, B, T, S)
+            xtv = _Var(xt)
+            if self.save:
+                def bwd_tr_in(xtv=xtv, x1=x1):
+                    g = self.E(M, D); ops.row_map(xtv.g, g, 0, B, S, T)
+                    self.acc(x1, g)
+                self.tape.append(bwd_tr_in)
+            if i == 0:
+                xt2 = self.E(M, D); ops.add_rows(xt, tpe_rows, xt2)
+                xt2v = _Var(xt2)
+                if self.save:
+                    def bwd_tpe(a=xt2v, b=xtv):
+                        self.acc(b, a.g)
+                    self.tape.append(bwd_tpe)
+                xtv = xt2v
+            qkvt = self.plinear(xtv, pre + "attn_temp.qkv.weight", "rows", 3)
+            at = self.attention(qkvt, T, "packed")
+            yt = self.plinear(at, pre + "attn_temp.proj.weight", "cols")
+            ytb = self.E(M, D); ops.row_map(yt.d, ytb, 0, B, S, T)                        # back to (t, s) rows
+            gt = self.E(M, D); ops.gate_mul(ytb, gt, sl(2), sl(2), bs, D, rps, 0)
+            x2d = self.E(M, D); ops.add_rows(x1.d, gt, x2d)
+            x2 = _Var(x2d)
+            if self.save:
+                def bwd_temp_out(x2=x2, x1=x1, yt=yt, ytb=ytb, dsl=dsl, sl=sl):
+                    g = x2.g
+                    ops.group_colsum(g, None, y=ytb, out2=dsl(2), D=D, S=rps, St=0, grouped=True, o_bstride=bs, o_segstride=0)
+                    gg = self.E(M, D); ops.gate_mul(g, gg, sl(2), sl(2), bs, D, rps, 0)
+                    gy = self.E(M, D); ops.row_map(gg, gy, 0, B, T, S)
+                    yt.g = gy
+                    self.acc(x1, g)
+                self.tape.append(bwd_temp_out)
+            # text cross-attention, un-gated
+            q = self.plinear(x2, pre + "cross_attn.q_linear.weight", "rows", 1)
+            kv = self.plinear(ye, pre + "cross_attn.kv_linear.weight", "rows", 2)
+            co = self.attention(q, B, "cross", kv=kv, kv_len=kv_len, L=L)
+            x3 = self.plinear(co, pre + "cross_attn.proj.weight", "cols", residual=x2)
+            # MLP, gated
+            hm = self.ln_mod(x3, sl(3), sl(4), bs, rps, dsl(3), dsl(4), bs)
+            x4 = self.mlp(hm, pre + "mlp.", residual=x3, gate=(sl(5), bs, rps), dgate=dsl(5))
+            h = x4
+
+        # ---- final layer: LN -> modulate(table + t) -> Linear -> unpatchify (blocks.py:585-625, stdit.py:313-334) ----
+        modf = (self.W("final_layer.scale_shift_table").float().view(1, 2 * D) + torch.cat([tf32, tf32], dim=1)).contiguous()
+        dmodf = torch.zeros(B, 2 * D, dtype=F32, device=dev) if self.save else None
+        if self.save:
+            def bwd_modf():
+                self.G("final_layer.scale_shift_table").view(-1).add_(dmodf.sum(0))
+                dt_final.add_(dmodf)
+            self.tape.append(bwd_modf)
+        hf = self.ln_mod(h, modf[:, :D], modf[:, D:], 2 * D, rps, None if dmodf is None else dmodf[:, :D], None if dmodf is None else dmodf[:, D:], 2 * D)
+        Co = m.out_channels
+        NO = pt * ph * pw * Co
+        NP = (NO + 63) // 64 * 64           # the input-gradient GEMM contracts over the outputs: pad them to a whole K-tile
+        wf, bf_ = self.W("final_layer.linear.weight"), self.W("final_layer.linear.bias")
+        wfp = torch.zeros(NP, D, dtype=BF16, device=dev); wfp[:NO] = wf
+        bfp = torch.zeros(NP, dtype=BF16, device=dev); bfp[:NO] = bf_
+        ob = self.E(M, NP)
+        ops.gemm(hf.d, wfp, ob, bfp)
+        outv = _Var(ob)
+        if self.save:
+            def bwd_final():
+                g_ = outv.g                                     # [M, NP], columns >= NO are zero
+                ops.group_colsum(g_[:, :NO], self.G("final_layer.linear.bias"), D=NO)
+                ops.linear_dw(g_[:, :NO], hf.d, self.G("final_layer.linear.weight"), accumulate=True)
+                dx = self.E(M, D)
+                ops.gemm(g_, wfp.t().contiguous(), dx, None)
+                self.acc(hf, dx)
+            self.tape.append(bwd_final)
+        self._out_var, self._out_dims = outv, (B, T, Hh // ph, Ww // pw, pt, ph, pw, Co)
+        o = outv.d[:, :NO].reshape(B, T, Hh // ph, Ww // pw, pt, ph, pw, Co).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, Co, T * pt, Hh, Ww)
+        return o.float()
+
+    def backward(self, dout):
+        B, T, Hp, Wp, pt, ph, pw, Co = self._out_dims
+        NO = pt * ph * pw * Co
+        g = torch.zeros(self._out_var.d.shape, dtype=BF16, device=self.dev)
+        g[:, :NO] = dout.to(torch.float32).view(B, Co, T, pt, Hp, ph, Wp, pw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(-1, NO)
+        self._out_var.g = g
+        while self.tape:
+            self.tape.pop()()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training workflow: LatentDiffusion.p_losses (iddpm3d.py:1332-1413) on pre-encoded batches
+# ---------------------------------------------------------------------------------------------------------------------
+class OpenSoraScheduler:
+    """IDDPMScheduler.register_schedule (iddpm3d.py:188-290) on get_named_beta_schedule("linear", T) (:100-125): float32 betas, then the
+    posterior tables in float64 (np.append(1.0, ...) promotes), as the reference's numpy arithmetic leaves them.  The yaml's
+    linear_start / linear_end are accepted and, as in the reference (LatentDiffusion.__init__ :987-989 passes given_betas), NOT used."""
+
+    def __init__(self, timesteps: int = 1000, linear_start=None, linear_end=None, **unused):
+        self.num_timesteps = int(timesteps)
+        scale = 1000 / timesteps
+        betas = np.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=np.float64).astype(np.float32)
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        tab = np.stack([np.sqrt(ac), np.sqrt(1.0 - ac), betas * np.sqrt(ac_prev) / (1.0 - ac), (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+                        np.log(np.append(post_var[1], post_var[1:])), np.log(betas), np.zeros_like(post_var), np.zeros_like(post_var)], axis=1)
+        tab[0, 6] = 1.0          # t == 0: the decoder-NLL branch of _vb_terms_bpd
+        self.table = torch.from_numpy(tab.astype(np.float64))            # [T, 8] fp64: the coef rows vt_opensora_loss wants
+        self._dev = {}
+
+    def coef(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device not in self._dev:
+            self._dev[t.device] = self.table.to(t.device)
+        return self._dev[t.device][t].contiguous()
+
+
+class _OpenSoraLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, x0, noise, coef):
+        loss3 = torch.empty(3, dtype=torch.float64, device=out.device)
+        dout = torch.empty_like(out)
+        ops.opensora_loss(out.contiguous(), x0, noise, coef, loss3, dout)
+        ctx.save_for_backward(dout)
+        ctx.parts = loss3
+        return loss3[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dout,) = ctx.saved_tensors
+        return dout * gout, None, None, None
+
+
+class OpenSoraFlow(nn.Module):
+    """videotuna.models.opensora.models.iddpm3d.LatentDiffusion for the training path: unet_config (STDiT), diffusion_scheduler_config;
+    batches are pre-encoded {"latents" [B,4,T,H,W], "y" [B,1,L,4096] (T5 embeddings), "mask" [B,L]}"""
+
+    def __init__(self, unet_config=None, diffusion_scheduler_config=None, base_learning_rate: float = 2e-5, logdir=None, **ignored):
+        super().__init__()
+        from .config import instantiate_from_config
+        self.model = instantiate_from_config(unet_config)
+        self.model.bfloat16()
+        self.scheduler = instantiate_from_config(diffusion_scheduler_config) if diffusion_scheduler_config is not None else OpenSoraScheduler()
+        self.diffusion_scheduler = self.scheduler
+        self.num_timesteps = self.scheduler.num_timesteps
+        self.learning_rate = base_learning_rate
+        self.logdir, self.lora_args, self.global_step = logdir, [], 0
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def configure_optimizers(self):
+        from .optim import FusedAdamW
+        ts = self.model.enable_training()
+        return FusedAdamW(ts.params, lr=self.learning_rate, fullft_state=ts)
+
+    def loss_from(self, x0, y, mask, t, noise):
+        x0 = x0.to(torch.float32).contiguous(); noise = noise.to(torch.float32).contiguous()
+        coef = self.scheduler.coef(t)
+        x_t = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device)
+        ops.q_sample(x0, noise, coef[:, 0].float().contiguous(), coef[:, 1].float().contiguous(), None, x_t)
+        out = self.model(x_t, t, y, mask)
+        return _OpenSoraLoss.apply(out, x0, noise, coef)
+
+    def training_step(self, batch, batch_idx=0):
+        if "latents" not in batch:
+            raise RuntimeError("the OpenSora path takes pre-encoded batches {'latents','y','mask'}: its VAE and T5 are outside this engine's hot path")
+        x0 = batch["latents"]
+        t = torch.randint(0, self.num_timesteps, (x0.shape[0],), device=x0.device).long()
+        return self.loss_from(x0, batch["y"], batch.get("mask"), t, torch.randn(x0.shape, dtype=torch.float32, device=x0.device))

@@ -153,41 +153,13 @@ def _is_conv(shape) -> bool:
     return len(shape) in (4, 5)
 
 
-class UNetModel(nn.Module):
-    """Constructor keys of the reference's UNetModel (openaimodel3d.py:341-372); options the VideoCrafter2 recipes leave off are
-    refused instead of ignored."""
+class FlatParamModule(nn.Module):
+    """A module whose parameters (reference names and logical shapes, given as an ordered {name: shape} dict) are views of ONE flat bf16
+    buffer -- convolution weights in channels-last storage --, with an optional training state next to it (fp32 master + fp32 gradient
+    buffer, one fused AdamW launch).  Shared by the VideoCrafter2 UNet and the OpenSora STDiT."""
 
-    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
-                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None, use_scale_shift_norm=False,
-                 resblock_updown=False, num_heads=-1, num_head_channels=-1, transformer_depth=1, use_linear=False, use_checkpoint=False,
-                 temporal_conv=False, tempspatial_aware=False, temporal_attention=True, temporal_selfatt_only=True,
-                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
-                 addition_attention=False, use_image_attention=False, temporal_transformer_depth=1, fps_cond=False,
-                 text_context_len: int = 77):
-        super().__init__()
-        unsupported = dict(use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, tempspatial_aware=tempspatial_aware,
-                           use_relative_position=use_relative_position, use_causal_attention=use_causal_attention,
-                           use_image_attention=use_image_attention, not_use_linear=not use_linear, not_conv_resample=not conv_resample,
-                           not_selfatt_only=not temporal_selfatt_only, dropout=dropout != 0.0, depth=transformer_depth != 1 or temporal_transformer_depth != 1,
-                           dims=dims != 2, num_heads=num_heads != -1)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(f"vt355 UNetModel implements the VideoCrafter2 recipe (configs/001_videocrafter2); unsupported options: {bad}")
-        if num_head_channels != 64:
-            raise NotImplementedError("the attention kernels are built for num_head_channels = 64")
-        if model_channels % 64 or context_dim is None or context_dim % 64:
-            raise ValueError("model_channels and context_dim must be multiples of 64 (one K-tile of the GEMM / convolution kernels)")
-        if temporal_attention and (temporal_length is None or 32 % temporal_length):
-            raise ValueError("temporal_length must divide 32 (packed temporal attention, csrc/attn_small.hip)")
-        self.config = SimpleNamespace(in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
-                                      num_res_blocks=num_res_blocks, attention_resolutions=tuple(attention_resolutions),
-                                      channel_mult=tuple(channel_mult), context_dim=context_dim, num_head_channels=num_head_channels,
-                                      temporal_conv=temporal_conv, temporal_attention=temporal_attention, temporal_length=temporal_length,
-                                      addition_attention=addition_attention, fps_cond=fps_cond, use_checkpoint=use_checkpoint,
-                                      text_context_len=text_context_len)
-        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
-        self.structure = build_structure(self.config)
-        self.shapes = _param_shapes(self.config, self.structure)
+    def _setup_flat(self, shapes: Dict[str, tuple]):
+        self.shapes = shapes
         self.offsets: Dict[str, int] = {}
         off = 0
         for n, shp in self.shapes.items():
@@ -249,26 +221,12 @@ class UNetModel(nn.Module):
         return out
 
     def load_state_dict(self, sd, strict: bool = True, **kw):
-        out = super().load_state_dict({k: v.to(BF16) for k, v in sd.items()}, strict=strict, **kw)
+        out = super().load_state_dict({k: (v.to(BF16) if k in self.shapes else v) for k, v in sd.items()}, strict=strict, **kw)
         if self.train_state is not None:
             self.train_state.flat.copy_(self.flat_bf16)
             self.train_state.version += 1
         self._packed = None
         return out
-
-    def init_weights(self, seed: int = 0):
-        """seeded random init for synthetic runs (no checkpoints offline); nothing is left at the reference's zero init"""
-        g = torch.Generator().manual_seed(seed)
-        with torch.no_grad():
-            for n, p in self._plist.items():
-                shp = self.shapes[n]
-                if len(shp) == 1:
-                    w = torch.randn(shp, generator=g) * 0.1 + (1.0 if n.endswith("weight") else 0.0)
-                else:
-                    w = torch.randn(shp, generator=g) * (0.7 / math.sqrt(math.prod(shp[1:])))
-                p.copy_(w.to(p.device, BF16))
-        self._packed = None
-        return self
 
     def enable_training(self):
         """full fine-tuning state: fp32 master copy and fp32 gradient buffer next to the flat bf16 parameters; hand
@@ -290,6 +248,57 @@ class UNetModel(nn.Module):
     @property
     def device(self):
         return self.flat_bf16.device
+
+
+class UNetModel(FlatParamModule):
+    """Constructor keys of the reference's UNetModel (openaimodel3d.py:341-372); options the VideoCrafter2 recipes leave off are
+    refused instead of ignored."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0.0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, context_dim=None, use_scale_shift_norm=False,
+                 resblock_updown=False, num_heads=-1, num_head_channels=-1, transformer_depth=1, use_linear=False, use_checkpoint=False,
+                 temporal_conv=False, tempspatial_aware=False, temporal_attention=True, temporal_selfatt_only=True,
+                 use_relative_position=True, use_causal_attention=False, temporal_length=None, use_fp16=False,
+                 addition_attention=False, use_image_attention=False, temporal_transformer_depth=1, fps_cond=False,
+                 text_context_len: int = 77):
+        super().__init__()
+        unsupported = dict(use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, tempspatial_aware=tempspatial_aware,
+                           use_relative_position=use_relative_position, use_causal_attention=use_causal_attention,
+                           use_image_attention=use_image_attention, not_use_linear=not use_linear, not_conv_resample=not conv_resample,
+                           not_selfatt_only=not temporal_selfatt_only, dropout=dropout != 0.0, depth=transformer_depth != 1 or temporal_transformer_depth != 1,
+                           dims=dims != 2, num_heads=num_heads != -1)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"vt355 UNetModel implements the VideoCrafter2 recipe (configs/001_videocrafter2); unsupported options: {bad}")
+        if num_head_channels != 64:
+            raise NotImplementedError("the attention kernels are built for num_head_channels = 64")
+        if model_channels % 64 or context_dim is None or context_dim % 64:
+            raise ValueError("model_channels and context_dim must be multiples of 64 (one K-tile of the GEMM / convolution kernels)")
+        if temporal_attention and (temporal_length is None or 32 % temporal_length):
+            raise ValueError("temporal_length must divide 32 (packed temporal attention, csrc/attn_small.hip)")
+        self.config = SimpleNamespace(in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
+                                      num_res_blocks=num_res_blocks, attention_resolutions=tuple(attention_resolutions),
+                                      channel_mult=tuple(channel_mult), context_dim=context_dim, num_head_channels=num_head_channels,
+                                      temporal_conv=temporal_conv, temporal_attention=temporal_attention, temporal_length=temporal_length,
+                                      addition_attention=addition_attention, fps_cond=fps_cond, use_checkpoint=use_checkpoint,
+                                      text_context_len=text_context_len)
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.structure = build_structure(self.config)
+        self._setup_flat(_param_shapes(self.config, self.structure))
+
+    def init_weights(self, seed: int = 0):
+        """seeded random init for synthetic runs (no checkpoints offline); nothing is left at the reference's zero init"""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for n, p in self._plist.items():
+                shp = self.shapes[n]
+                if len(shp) == 1:
+                    w = torch.randn(shp, generator=g) * 0.1 + (1.0 if n.endswith("weight") else 0.0)
+                else:
+                    w = torch.randn(shp, generator=g) * (0.7 / math.sqrt(math.prod(shp[1:])))
+                p.copy_(w.to(p.device, BF16))
+        self._packed = None
+        return self
 
     # ---- forward ----
     def forward(self, x, timesteps, context=None, features_adapter=None, fps=16, **kwargs):

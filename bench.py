@@ -193,6 +193,62 @@ def bench_vc2(args):
         dist.destroy_process_group()
 
 
+def bench_stdit(args):
+    """BASELINE configs[0] at its stated size on the GPU (the config itself is a CPU-eager plumbing step in the reference): OpenSora v1.0
+    STDiT-XL/2, latents [B,4,16,32,32] (16x256x256 video), T5 embeddings [B,1,120,4096] with ragged masks, full fine-tune of 759.6 M
+    weights: q_sample -> STDiT -> mse + VB loss -> backward -> fused AdamW."""
+    from vt355 import ops
+    from vt355.ddp import init_from_env
+    from vt355.stdit import OpenSoraFlow
+    rank, local, world = init_from_env(os.environ.get("VT_DDP_BACKEND"))
+    assert world == args.gpus == 1, "the OpenSora line is single-GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    flow = OpenSoraFlow(unet_config=dict(target="vt355.stdit.STDiT_XL_2", params=dict(space_scale=0.5, time_scale=1.0, input_size=[16, 32, 32],
+                                                                                      class_dropout_prob=0.0)),
+                        diffusion_scheduler_config=dict(target="vt355.stdit.OpenSoraScheduler", params=dict(timesteps=1000)),
+                        base_learning_rate=6e-6, use_scale=True, scale_b=0.7)
+    flow.model.init_weights(7)
+    flow.to(dev)
+    opt = flow.configure_optimizers()
+    B = args.micro_batch if args.micro_batch != 2 else 4          # the yaml's batch_size
+    dgen = torch.Generator(device=dev).manual_seed(20230211)
+    mask = torch.zeros(B, 120, dtype=torch.int64, device=dev)
+    for b in range(B):
+        mask[b, :20 + 25 * b] = 1
+    losses = []
+
+    def step():
+        opt.zero_grad()
+        z = torch.randn(B, 4, 16, 32, 32, device=dev, generator=dgen)
+        y = torch.randn(B, 1, 120, 4096, device=dev, generator=dgen).to(torch.bfloat16)
+        t = torch.randint(0, 1000, (B,), device=dev, generator=dgen)
+        z = z * flow.scale_arr[t].view(-1, 1, 1, 1, 1)
+        loss = flow.loss_from(z, y, mask, t, torch.randn(z.shape, device=dev, generator=dgen))
+        loss.backward()
+        losses.append(loss.detach())
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lv = [float(x) for x in torch.stack(losses[-args.steps:]).cpu()]
+    fwd_tflop = 5.64             # SURVEY 8(d): FlopCounterMode on the imported reference STDiT-XL/2, per sample
+    print(json.dumps({"metric": "finetune samples/sec, OpenSora-v1.0 STDiT-XL/2 16x256x256 full-FT bf16", "value": B * args.steps / elapsed,
+                      "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "OpenSora v1.0 STDiT-XL/2 (configs[0] at its stated size, NOT the headline config): latents "
+                                             f"[{B},4,16,32,32], T5 embeddings [{B},1,120,4096] with ragged masks, all 759.6 M weights trained",
+                                 "micro_batch": B, "weights": "seeded random init (no checkpoints offline)"},
+                      "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                      "step_tflops_algorithmic": 3.0 * fwd_tflop * B * args.steps / elapsed, "loss_first": lv[0], "loss_last": lv[-1]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +258,7 @@ def main():
     ap.add_argument("--accum", type=int, default=2)
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["2b", "5b", "vc2"], default="2b",
+    ap.add_argument("--model", choices=["2b", "5b", "vc2", "stdit"], default="2b",
                     help="2b = the benchmark (BASELINE configs[1]); 5b = CogVideoX-5B dimensions (48 heads, 42 layers, rotary q/k) -- "
                          "extra data point, labelled as such, never the headline line; vc2 = BASELINE configs[3], the VideoCrafter2 "
                          "320x512 UNet (full fine-tune of 1.41 B weights, latents [4,4,16,40,64]) -- its own metric line")
@@ -238,6 +294,8 @@ def main():
 
     if args.model == "vc2":
         return bench_vc2(args)
+    if args.model == "stdit":
+        return bench_stdit(args)
 
     from vt355 import ops
     from vt355.ddp import BucketedReducer, FlatGradReducer, broadcast_flat, init_from_env

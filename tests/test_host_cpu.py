@@ -430,3 +430,28 @@ def test_reference_yaml_files_load_unchanged(tmp_path, monkeypatch, yaml_name):
         assert sum(p.numel() for p in opt.params) == 2 * 4 * 2 * 4 * 64 and opt.defaults["lr"] == node["base_learning_rate"]
         kept = wf.on_save_checkpoint({"state_dict": dict(sd)})["state_dict"]
         assert set(kept) == lora                            # LoRA-only filter
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference tree only exists in the build container")
+def test_videocrafter2_and_opensora_yaml_files_load_unchanged():
+    """configs/001_videocrafter2/vc2_t2v_320x512.yaml (flow style) and configs/003_opensora/opensorav10_256x256.yaml (model style) from the
+    reference tree AS THEY ARE: load_yaml -> instantiate_from_config through the target remap -> the denoisers at their real sizes with the
+    reference's parameter counts (UNet 1 413 M, STDiT-XL/2 759.6 M).  The frozen first / cond stage
+    nodes (VAE, CLIP / T5) are accepted and not built (outside the hot path)."""
+    from vt355.config import instantiate_from_config, load_yaml
+    from vt355.lvdm import LVDMFlow
+    from vt355.stdit import OpenSoraFlow
+    vc2 = instantiate_from_config(load_yaml("/root/reference/configs/001_videocrafter2/vc2_t2v_320x512.yaml")["flow"])
+    assert isinstance(vc2, LVDMFlow) and vc2.use_scale and abs(vc2.scale_arr[999].item() - 0.7) < 1e-6 and vc2.parameterization == "eps"
+    n = sum(p.numel() for p in vc2.model.parameters())
+    assert abs(n - 1413.3e6) < 0.5e6, n
+    assert vc2.scheduler.num_timesteps == 1000 and abs(vc2.scheduler.alphas_cumprod[0].item() - 0.99915) < 1e-5
+    with pytest.raises(NotImplementedError):
+        instantiate_from_config(load_yaml("/root/reference/configs/001_videocrafter2/vc2_t2v_lora.yaml")["model"])      # lora_args: not built
+    osr = instantiate_from_config(load_yaml("/root/reference/configs/003_opensora/opensorav10_256x256.yaml")["model"])
+    assert isinstance(osr, OpenSoraFlow) and osr.use_scale
+    m = osr.model
+    assert (m.depth, m.hidden_size, m.num_heads, m.num_temporal, m.num_spatial) == (28, 1152, 16, 16, 256)
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 759.6e6) < 0.5e6, n
+    assert callable(osr.configure_optimizers) and osr.scheduler.num_timesteps == 1000

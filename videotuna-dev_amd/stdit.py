@@ -566,7 +566,8 @@ class OpenSoraFlow(nn.Module):
     """videotuna.models.opensora.models.iddpm3d.LatentDiffusion for the training path: unet_config (STDiT), diffusion_scheduler_config;
     batches are pre-encoded {"latents" [B,4,T,H,W], "y" [B,1,L,4096] (T5 embeddings), "mask" [B,L]}"""
 
-    def __init__(self, unet_config=None, diffusion_scheduler_config=None, base_learning_rate: float = 2e-5, logdir=None, **ignored):
+    def __init__(self, unet_config=None, diffusion_scheduler_config=None, base_learning_rate: float = 2e-5, logdir=None,
+                 use_scale: bool = False, scale_a: float = 1.0, scale_b: float = 0.3, mid_step: int = 400, fix_scale_bug: bool = False, **ignored):
         super().__init__()
         from .config import instantiate_from_config
         self.model = instantiate_from_config(unet_config)
@@ -576,6 +577,11 @@ class OpenSoraFlow(nn.Module):
         self.num_timesteps = self.scheduler.num_timesteps
         self.learning_rate = base_learning_rate
         self.logdir, self.lora_args, self.global_step = logdir, [], 0
+        self.use_scale = use_scale
+        if use_scale:       # iddpm3d.py:1021-1035, applied in forward() :1275-1276 before p_losses
+            step = self.num_timesteps - mid_step if fix_scale_bug else self.num_timesteps
+            self.register_buffer("scale_arr", torch.tensor(np.concatenate((np.linspace(scale_a, scale_b, mid_step), np.full(step, scale_b))),
+                                                           dtype=torch.float32))
 
     @property
     def device(self):
@@ -599,4 +605,6 @@ class OpenSoraFlow(nn.Module):
             raise RuntimeError("the OpenSora path takes pre-encoded batches {'latents','y','mask'}: its VAE and T5 are outside this engine's hot path")
         x0 = batch["latents"]
         t = torch.randint(0, self.num_timesteps, (x0.shape[0],), device=x0.device).long()
+        if self.use_scale:
+            x0 = x0.to(torch.float32) * self.scale_arr[t].view(-1, 1, 1, 1, 1)
         return self.loss_from(x0, batch["y"], batch.get("mask"), t, torch.randn(x0.shape, dtype=torch.float32, device=x0.device))

@@ -86,7 +86,13 @@ def cpu_baseline(seconds_budget=40.0):
     (hv.sum() + ht.sum()).backward()
     dt = time.time() - t0
     threads = torch.get_num_threads()
-    return {"value": 1.0 / (30.0 * dt), "unit": "samples/s", "cores": threads, "kind": "port",
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": 1.0 / (30.0 * dt), "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
             "sample": f"1 of 30 DiT blocks, fwd+bwd, B=1, S=17776, fp32 eager PyTorch-CPU oracle, {dt:.1f} s measured, x30",
             "block_seconds": dt, "host_cpus": os.cpu_count()}
 
@@ -470,23 +476,33 @@ def main():
     if rank == 0:
         S, d = St + Fr * (Hh // 2) * (Ww // 2), model.inner_dim
         alg = {"attn_bwd": 8.0 * S * S * d * B, "attn_fwd": 4.0 * S * S * d * B}     # algorithmic FLOPs per launch
+        work = ops.profile_work()
         kern = {}
         for name, (ms, n) in prof.items():
             kern[name] = {"avg_ms": ms, "launches": n}
             if name in alg:
                 kern[name]["tflops_algorithmic"] = alg[name] / ms / 1e9
+            elif name in work:
+                kern[name]["tflops_algorithmic"] = work[name] / (ms * n) / 1e9
         dom = "attn_bwd"
         ach = kern[dom]["tflops_algorithmic"] if dom in kern else None
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the figure
-        # comes from the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh), corrected as
-        # MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, KiB units).
-        traffic = None
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
+        # the committed rocprofv3 --pmc summary of this same command (tools/pmc_bench.sh), corrected as MI355X_MICROARCH.md
+        # prescribes (FETCH_SIZE x2 on gfx950, KiB units).  The summary records the hash of the kernel source it was measured on: a
+        # figure from another version of the kernel is NOT quoted (traffic = null).
+        traffic, traffic_note = None, "no PMC summary for this kernel source"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")) as f:
-                tr = json.load(f)["traffic"]
-            key = [k for k in tr if "attn_bwd_hd64_kernel" in k][0]
-            if args.micro_batch == 2 and args.layers == 30 and args.model == "2b":
-                traffic = tr[key]["hbm_bytes_per_launch"]
+            import hashlib
+            src = hashlib.sha256(open(os.path.join(ROOT, "videotuna-dev_amd", "csrc", "attn_bwd.hip"), "rb").read()).hexdigest()[:16]
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_bench_summary.json")) as f:
+                summ = json.load(f)
+            if summ.get("provenance", {}).get("attn_bwd_src_sha16") != src:
+                traffic_note = "profiles/r02_pmc_bench_summary.json was measured on another version of attn_bwd.hip: not quoted"
+            elif args.micro_batch == 2 and args.layers == 30 and args.model == "2b":
+                key = [k for k in summ["traffic"] if "attn_bwd_hd64_kernel" in k][0]
+                traffic = summ["traffic"][key]["hbm_bytes_per_launch"]
+                traffic_note = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r02_pmc_bench_summary.json, same kernel "
+                                "source " + src + "); algorithmic bytes are 1.1 GB, the rest are the fp32 dQ atomics and hand-off tiles")
         except Exception:
             traffic = None
         from vt355 import engine as _eng
@@ -518,11 +534,17 @@ def main():
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
             "roofline": {"bound": "mfma", "kernel": "attn_bwd_hd64_kernel", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": (ach / 2500.0) if ach else None, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_summary.json; "
-                                         "~9.5 GB of it are fp32 dQ atomics -- one set per PAIR of key blocks -- most of the rest hand-off tiles "
-                                         "evicted from the L2; algorithmic bytes are 1.1 GB)",
+                         "traffic_unit": traffic_note,
                          "note": "algorithmic FLOPs per launch 8*S^2*d*B (dQ,dK,dV products; P recompute not counted)"},
+            "roofline_more": [
+                {"bound": "mfma", "kernel": "attn_fwd_hd64_kernel", "achieved": kern.get("attn_fwd", {}).get("tflops_algorithmic"), "peak": 2500.0,
+                 "unit": "TFLOP/s", "frac": (kern["attn_fwd"]["tflops_algorithmic"] / 2500.0) if "attn_fwd" in kern else None},
+                {"bound": "mfma", "kernel": "gemm_tn_* (every Linear with >= 4096 rows, forward and dX)", "achieved": kern.get("gemm", {}).get("tflops_algorithmic"),
+                 "peak": 2500.0, "unit": "TFLOP/s", "frac": (kern["gemm"]["tflops_algorithmic"] / 2500.0) if kern.get("gemm", {}).get("tflops_algorithmic") else None}],
             "kernels": kern,
+            "ddp": {"backend": (dist.get_backend() if world > 1 else None), "world_size_seen": (dist.get_world_size() if world > 1 else 1),
+                    "allreduce_bytes_per_step": int(st.grad.numel() * 4) if world > 1 else 0,
+                    "dq_chains": bool(ops.attn_bwd_chain_workspace(args.micro_batch, model.config.num_attention_heads, S, dev) is not None)},
             "loss_last": loss_vals[-1], "loss_first": loss_vals[0],
         }
         if world == 1 and not args.no_cpu_baseline:

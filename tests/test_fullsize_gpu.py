@@ -140,13 +140,69 @@ def test_one_full_size_block_train_step(dev, family):
     pred = O.get_velocity(out_ref, nref, t, abar)
     loss_ref = torch.mean(((1 / (1 - abar[t])).view(-1, 1, 1, 1, 1) * (pred - x0) ** 2).reshape(1, -1), dim=1).mean()
     loss_ref.backward()
-    assert relerr(out, out_ref)[0] < 2e-2
-    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 1e-2, (loss.item(), loss_ref.item())
     gref = torch.cat([Lo[k].grad.reshape(-1) for k in Lo])
     gdev = torch.cat([st.view(st.grad, l, kd, j).reshape(-1).cpu() for (l, kd, j) in st._index])
     cos = F.cosine_similarity(gdev, gref, dim=0).item()
     l2 = ((gdev - gref).norm() / gref.norm()).item()
+    lrel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    # observed values are printed (run with -s) and recorded in DESIGN.md 6; north_star: loss within 1e-3 of the reference
+    print(f"[full-size block {family} LoRA] out rel-L2 {relerr(out, out_ref)[0]:.3e}  loss dev {loss.item():.6f} oracle {loss_ref.item():.6f} "
+          f"rel {lrel:.2e}  LoRA grads cos {cos:.5f} rel-L2 {l2:.3e}")
+    assert relerr(out, out_ref)[0] < 2e-2
+    assert lrel < 1e-3, (loss.item(), loss_ref.item())        # north_star: loss within 1e-3 of the reference (observed 3.5e-5 .. 6.3e-5, r02)
     assert cos > 0.995 and l2 < 0.1, (cos, l2)
+
+
+def test_one_full_size_block_full_finetune_all_parameter_grads(dev):
+    """BASELINE configs[2] at size: CogVideoX-2B dimensions (d 1920, 30 heads, S 17 776, text 226 x 4096), ONE block, FULL fine-tune:
+    loss and the gradient of EVERY parameter (block weights, adaLN linears, embeddings, final layers) against the fp32 oracle on the
+    same bf16-rounded weights."""
+    from vt355.dit import CogVideoXTransformer3DModel
+    from vt355.fullft import enable_full_finetune
+    from vt355.scheduler import CogVideoXDPMScheduler
+    from vt355.workflow import _LossFn
+    cfg = O.DiTConfig(num_layers=1)
+    model = CogVideoXTransformer3DModel(num_layers=1).init_weights(3).to(dev)
+    ft = enable_full_finetune(model)
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(1, 13, 16, 60, 90, generator=g)
+    text = (torch.randn(1, 226, 4096, generator=g) * 0.2).to(BF)
+    noise = torch.randn(x0.shape, generator=g)
+    t = torch.tensor([437])
+    sched = CogVideoXDPMScheduler()
+    noisy = sched.add_noise(x0.to(dev), noise.to(dev), t.to(dev))
+    out = model(hidden_states=noisy, encoder_hidden_states=text.to(dev), timestep=t.to(dev))[0]
+    sa, sb, w = sched.coefficients(t.to(dev))
+    loss = _LossFn.apply(out, noisy, x0.to(dev), sa, sb, w)
+    ft.grad.zero_(); loss.backward()
+    Pref = {k: v.detach().float().cpu().requires_grad_(True) for k, v in model.state_dict().items()}
+    abar = O.alphas_cumprod_cogvideox().float()
+    nref = noisy.float().cpu()
+    out_ref = O.dit_forward(Pref, cfg, nref, text.float(), t)
+    pred = O.get_velocity(out_ref, nref, t, abar)
+    loss_ref = torch.mean(((1 / (1 - abar[t])).view(-1, 1, 1, 1, 1) * (pred - x0) ** 2).reshape(1, -1), dim=1).mean()
+    loss_ref.backward()
+    lrel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    worst, bad = (None, 1.0, 0.0), []
+    for name in ft.names:
+        gd = ft.g(name).cpu().float().reshape(-1)
+        gr = Pref[name].grad.reshape(-1)
+        if name.endswith("norm_k.bias"):           # exact gradient is 0 (softmax is shift-invariant): only its size is checked
+            assert gd.norm() < 0.05 * ft.g(name.replace("bias", "weight")).norm().item() + 1e-6, name
+            continue
+        cos = F.cosine_similarity(gd, gr, dim=0).item()
+        rel = ((gd - gr).norm() / (gr.norm() + 1e-30)).item()
+        if cos < worst[1]:
+            worst = (name, cos, rel)
+        if not (cos > 0.99 and rel < 0.15):
+            bad.append((name, round(cos, 4), round(rel, 4)))
+    gd = ft.grad.cpu().float()
+    gr = torch.cat([Pref[n].grad.reshape(-1) for n in ft.names])
+    tot = F.cosine_similarity(gd, gr, dim=0).item()
+    print(f"[full-size block 2b FULL-FT] loss dev {loss.item():.6f} oracle {loss_ref.item():.6f} rel {lrel:.2e}; whole gradient cos {tot:.5f}; "
+          f"worst parameter {worst[0]} cos {worst[1]:.4f} rel-L2 {worst[2]:.3e}; {len(ft.names)} tensors")
+    assert lrel < 1e-3 and tot > 0.999                          # observed 6.2e-5 (r02)
+    assert not bad, bad[:12]
 
 
 def test_t5_xxl_layer_fullsize(dev):

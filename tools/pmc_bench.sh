@@ -28,7 +28,14 @@ stats = {}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         stats[r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
-json.dump({"traffic": res, "kernel_stats": stats}, open(out + "/summary.json", "w"), indent=1)
+import hashlib, os
+root = os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[0]))) if False else os.getcwd()
+def sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+prov = {"attn_bwd_src_sha16": sha(os.path.join(root, "videotuna-dev_amd/csrc/attn_bwd.hip")),
+        "attn_fwd_src_sha16": sha(os.path.join(root, "videotuna-dev_amd/csrc/attn_fwd.hip")),
+        "lib_sha16": sha(os.path.join(root, "videotuna-dev_amd/libvt355.so")), "command": "python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline"}
+json.dump({"provenance": prov, "traffic": res, "kernel_stats": stats}, open(out + "/summary.json", "w"), indent=1)
 for k in sorted(res, key=lambda k: -res[k]["hbm_bytes_per_launch"] * res[k]["launches"])[:8]:
     print(k[:60], res[k])
 PY

@@ -26,9 +26,11 @@ _PROFILED = ("attn_fwd", "attn_bwd", "conv", "conv_dw")
 
 
 def profile_reset(on: bool):
+    """on: start a fresh measurement; off: stop recording (what was collected stays readable until the next start)"""
     _PROFILE["on"] = on
-    _PROFILE["events"] = {}
-    _PROFILE["work"] = {}
+    if on:
+        _PROFILE["events"] = {}
+        _PROFILE["work"] = {}
 
 
 def profile_work():
@@ -64,6 +66,17 @@ class _timed:
             _PROFILE["events"].setdefault(self.name, []).append((self.a, b))
 
 
+class _NoTime:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOTIME = _NoTime()
+
+
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -97,13 +110,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     if not out_f32:
         _req(out, BF16, "out", 2)
     lib = load_library()
-    check(lib.vt_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
-                           M, N, K, _p(bias), epilogue, int(out_f32),
-                           _p(residual), 0 if residual is None else residual.stride(0), r_mod,
-                           _p(gate_txt), _p(gate_vid), gate_bstride, S, St,
-                           _p(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
-                           _p(pre_act_in), 0 if pre_act_in is None else pre_act_in.stride(0), _stream()),
-          "vt_gemm_bf16")
+    with _timed("gemm", 2.0 * M * N * K if (_PROFILE["on"] and M >= 4096) else 0.0) if (_PROFILE["on"] and M >= 4096) else _NOTIME:
+        check(lib.vt_gemm_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+                               M, N, K, _p(bias), epilogue, int(out_f32),
+                               _p(residual), 0 if residual is None else residual.stride(0), r_mod,
+                               _p(gate_txt), _p(gate_vid), gate_bstride, S, St,
+                               _p(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
+                               _p(pre_act_in), 0 if pre_act_in is None else pre_act_in.stride(0), _stream()),
+              "vt_gemm_bf16")
     return out
 
 

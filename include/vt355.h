@@ -337,6 +337,17 @@ int vt_attn_gen_bwd(const void* q, const void* k, const void* v, const void* o, 
 int vt_opensora_loss(const float* out, const float* x0, const float* noise, const double* coef, double* loss3, float* dout,
                      long long per_channel, int C, int B, float grad_scale, void* stream);
 
+/* FP8 (OCP E4M3) GEMM with per-tensor scales, real fp8 MFMA (csrc/gemm_fp8.hip): C (bf16) = (Aq Wq^T) * scale_a * scale_w + bias.
+ * Replaces: fp8_linear_forward (videotuna/models/hunyuan/hyvideo_t2v/modules/fp8_optimization.py:55-80), which keeps E4M3 weights with a
+ * per-tensor scale but de-quantises to bf16 for F.linear (weight-only emulation); north_star asks for fp8 MFMA (configs[4], a16).
+ * A, W: float8_e4m3fn bytes [M, lda] / [N, ldw]; scales: device fp32 scalars; K % 128 == 0, N % 4 == 0.
+ * vt_quantize_fp8: x bf16 -> e4m3 with scale = max|x| / 448 (fp8_optimization.py:58-60) written to scale[0] (given_scale != 0: scale[0] is
+ * an input, e.g. the checkpoint's fp8_scale); ws: device uint32 [1] scratch. */
+int vt_gemm_fp8(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const void* bias,
+                const float* scale_a, const float* scale_w, void* stream);
+int vt_quantize_fp8(const void* x, long long ldx, void* y, long long ldy, long long M, int K, float* scale, unsigned int* ws,
+                    int given_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

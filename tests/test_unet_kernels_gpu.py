@@ -310,3 +310,27 @@ def test_attn_gen_hd72_packed_temporal(dev, R, T):
 def test_attn_gen_hd128(dev, NB, H, Sq, Sk):
     """HunyuanVideo's head size (hyvideo_t2v/modules/attenion.py:60-156), short sequences"""
     _gen_case(dev, NB, H, Sq, Sk, 128, 128)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 384), (4096, 3072, 3072), (77, 12, 128)])
+def test_gemm_fp8_matches_dequantized_reference(dev, M, N, K):
+    """real fp8 MFMA vs the reference's emulation (hunyuan fp8_optimization.py:55-80: E4M3 weight x per-tensor scale, de-quantised, F.linear),
+    with the activation quantised the same way: bit-level agreement of the quantisers with torch's float8_e4m3fn cast, product within
+    fp32-accumulation noise"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) * 0.05); b = rb(torch.randn(N, generator=g))
+    aq, sa = ops.quantize_fp8(a.to(dev, BF)); wq, sw = ops.quantize_fp8(w.to(dev, BF))
+    sa_ref, sw_ref = a.abs().max() / 448.0, w.abs().max() / 448.0
+    assert abs(sa.item() - sa_ref.item()) < 1e-6 * sa_ref.item() and abs(sw.item() - sw_ref.item()) < 1e-6 * sw_ref.item()
+    aq_ref = (a / sa_ref).to(torch.float8_e4m3fn); wq_ref = (w / sw_ref).to(torch.float8_e4m3fn)
+    assert (aq.cpu().view(torch.uint8) != aq_ref.view(torch.uint8)).float().mean().item() < 1e-3       # rounding ties aside
+    ref = (aq.cpu().float() * sa.item()) @ (wq.cpu().float() * sw.item()).T + b
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.gemm_fp8(aq, wq, out, sa, sw, b.to(dev, BF))
+    close(out, ref, 1e-2, 1e-2 * ref.abs().max().item(), "fp8 GEMM")
+    # and against the unquantised product: the quantisation error of E4M3 (3 mantissa bits) on both operands
+    full = a @ w.T + b
+    rel = ((out.float().cpu() - full).norm() / full.norm()).item()
+    assert rel < 0.06, rel

@@ -791,3 +791,28 @@ def opensora_loss(out, x0, noise, coef, loss3, dout=None, grad_scale: float = 1.
         raise ValueError("out must be contiguous [B, 2C, ...] next to contiguous x0 / noise [B, C, ...]")
     check(load_library().vt_opensora_loss(out.data_ptr(), x0.data_ptr(), noise.data_ptr(), coef.data_ptr(), loss3.data_ptr(), _p(dout),
                                           x0.numel() // (B * C), C, B, grad_scale, _stream()), "vt_opensora_loss")
+
+
+FP8 = torch.float8_e4m3fn
+
+
+def quantize_fp8(x, scale: Optional[torch.Tensor] = None):
+    """x bf16 [M, K] -> (xq float8_e4m3fn [M, K], scale fp32 [1]) with scale = max|x| / 448 (or the given stored scale)"""
+    _req(x, BF16, "x", 2)
+    M, K = x.shape
+    y = torch.empty(M, K, dtype=FP8, device=x.device)
+    given = scale is not None
+    if not given:
+        scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1, dtype=torch.int32, device=x.device)
+    check(load_library().vt_quantize_fp8(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), M, K, scale.data_ptr(), ws.data_ptr(),
+                                         int(given), _stream()), "vt_quantize_fp8")
+    return y, scale
+
+
+def gemm_fp8(aq, wq, out, scale_a, scale_w, bias=None):
+    """out bf16 [M, N] = (aq [M, K] @ wq [N, K]^T) * scale_a * scale_w + bias on the fp8 matrix cores"""
+    _req(aq, FP8, "aq", 2); _req(wq, FP8, "wq", 2); _req(out, BF16, "out", 2)
+    check(load_library().vt_gemm_fp8(aq.data_ptr(), aq.stride(0), wq.data_ptr(), wq.stride(0), out.data_ptr(), out.stride(0), aq.shape[0],
+                                     wq.shape[0], aq.shape[1], _p(bias), scale_a.data_ptr(), scale_w.data_ptr(), _stream()), "vt_gemm_fp8")
+    return out

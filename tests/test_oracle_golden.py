@@ -379,3 +379,44 @@ def test_opensora_loss_with_vb_term_matches_reference():
     loss.backward()
     r = T("dmodel_out")
     assert (mo.grad - r).abs().max().item() < 1e-4 * r.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ HunyuanVideo blocks
+def test_hunyuan_block_oracle_matches_reference_blocks():
+    """oracle/hunyuan_oracle.py vs the reference's own MMDoubleStreamBlock / MMSingleStreamBlock (hyvideo_t2v/modules/models.py:21-393) run by
+    tests/golden/make_golden_hunyuan.py: outputs, input gradients (img, txt, vec), every parameter gradient (rows + checksums)"""
+    import hunyuan_oracle as HO
+    g = np.load(os.path.join(G, "hunyuan_blocks.npz"))
+    T = lambda k: torch.from_numpy(g[k]).double()
+    D, H = 256, 2
+    cos, sin, tv = T("cos"), T("sin"), torch.from_numpy(g["txt_valid"])
+
+    def check_grads(P, tag):
+        for n, p in P.items():
+            r = T(f"{tag}_g.{n}")
+            got = p.grad.reshape(p.shape[0], -1)[:r.shape[0]]
+            assert (got - r).abs().max().item() < 2e-4 * r.abs().max().item() + 1e-9, (tag, n)
+            cs = g[f"{tag}_c.{n}"]
+            assert abs(p.grad.abs().sum().item() - cs[1]) < 3e-4 * cs[1] + 1e-9, (tag, n)
+
+    Pd = {k: v.double().requires_grad_(True) for k, v in HO.init(HO.double_block_shapes(D, H), 1).items()}
+    img, txt, vec = T("img").requires_grad_(True), T("txt").requires_grad_(True), T("vec").requires_grad_(True)
+    io, to = HO.double_block(img, txt, vec, Pd, "", H, tv, cos, sin)
+    assert (io - T("d_img")).abs().max().item() < 2e-5 * T("d_img").abs().max().item()
+    valid = (T("d_gt").abs().sum(-1, keepdim=True) > 0).double()
+    assert ((to - T("d_txt")) * valid).abs().max().item() < 2e-5 * T("d_txt").abs().max().item()
+    ((io * T("d_gi")).sum() + (to * T("d_gt")).sum()).backward()
+    for got, k in ((img.grad, "d_dimg"), (txt.grad, "d_dtxt"), (vec.grad, "d_dvec")):
+        assert (got - T(k)).abs().max().item() < 2e-4 * T(k).abs().max().item(), k
+    check_grads(Pd, "d")
+
+    Ps = {k: v.double().requires_grad_(True) for k, v in HO.init(HO.single_block_shapes(D, H), 2).items()}
+    x = torch.cat([T("img"), T("txt")], 1).requires_grad_(True)
+    v2 = T("vec").requires_grad_(True)
+    xo = HO.single_block(x, v2, Ps, "", H, g["txt"].shape[1], tv, cos, sin)
+    vm = (T("s_gx").abs().sum(-1, keepdim=True) > 0).double()
+    assert ((xo - T("s_x")) * vm).abs().max().item() < 2e-5 * T("s_x").abs().max().item()
+    (xo * T("s_gx")).sum().backward()
+    assert (x.grad - T("s_dx")).abs().max().item() < 2e-4 * T("s_dx").abs().max().item()
+    assert (v2.grad - T("s_dvec")).abs().max().item() < 2e-4 * T("s_dvec").abs().max().item()
+    check_grads(Ps, "s")

@@ -348,6 +348,18 @@ int vt_gemm_fp8(const void* A, int lda, const void* W, int ldw, void* C, int ldc
 int vt_quantize_fp8(const void* x, long long ldx, void* y, long long ldy, long long M, int K, float* scale, unsigned int* ws,
                     int given_scale, void* stream);
 
+/* HunyuanVideo q/k preparation, head_dim 128 (csrc/qknorm128.hip): per-head RMSNorm(eps, weight [128]) of the q and k thirds of a fused
+ * [M, 3*H*128] projection, rotary embedding of the first S_rope positions of every sample (image tokens; cos / sin fp32 [S_rope, 128] | NULL),
+ * and the scatter of q^ | k^ | v into the joint [image; text] sequence: out row = (m / L) * Lout + row_off + m % L.  rstd fp32 [M, 2H].
+ * Replaces: img_attn_q_norm / img_attn_k_norm / apply_rotary_emb / torch.cat of MMDoubleStreamBlock.forward and q_norm / k_norm / the
+ * sliced rotary of MMSingleStreamBlock.forward (videotuna/models/hunyuan/hyvideo_t2v/modules/models.py:166-196, 351-361). */
+int vt_qk_rmsnorm_rope128_fwd(const void* qkv, long long ld, void* out, long long ldo, const void* gq, const void* gk, float* rstd,
+                              const float* rope_cos, const float* rope_sin, long long M, int H, int L, int Lout, int row_off,
+                              int S_rope, float eps, void* stream);
+int vt_qk_rmsnorm_rope128_bwd(const void* dout, long long lddo, const void* qkv, long long ld, void* dqkv, long long ldd, const void* gq,
+                              const void* gk, const float* rstd, const float* rope_cos, const float* rope_sin, float* dgq, float* dgk,
+                              long long M, int H, int L, int Lout, int row_off, int S_rope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

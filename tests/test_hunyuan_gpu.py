@@ -1,0 +1,179 @@
+"""HunyuanVideo blocks on the device (vt355.hunyuan) against the CPU oracle (oracle/hunyuan_oracle.py, pinned to the imported reference
+MMDoubleStreamBlock / MMSingleStreamBlock by tests/golden/hunyuan_blocks.npz) -- BASELINE configs[4], SURVEY 8(a) a16."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _rope_tables(S, gen):
+    ang = torch.rand(S, 64, generator=gen) * 6.28
+    return torch.repeat_interleave(ang.cos(), 2, dim=1).contiguous(), torch.repeat_interleave(ang.sin(), 2, dim=1).contiguous()
+
+
+@pytest.mark.parametrize("L,Lout,off,rope", [(24, 24, 0, True), (10, 37, 27, False), (27, 37, 0, True)])
+def test_qk_rmsnorm_rope128_matches_torch(dev, L, Lout, off, rope):
+    """vt_qk_rmsnorm_rope128 fwd / bwd vs a torch fp64 statement of RMSNorm (norm_layers.py:5-58) + apply_rotary_emb (posemb_layers.py:133-188)
+    + the placement into the joint sequence; the rope covers the first S_rope = L - 3 positions when L == Lout (single block: text rows at
+    the end are not rotated)"""
+    import hunyuan_oracle as HO
+    from vt355 import ops
+    gen = torch.Generator().manual_seed(5)
+    B, H = 2, 3
+    C = H * 128
+    S_rope = (L - 3 if L == Lout else L) if rope else 0
+    qkv = torch.randn(B * L, 3 * C, generator=gen).to(BF)
+    gq = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF); gk = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF)
+    cos, sin = _rope_tables(max(S_rope, 1), gen)
+    dout = torch.randn(B * Lout, 3 * C, generator=gen).to(BF)
+    out = torch.full((B * Lout, 3 * C), 7.0, dtype=BF, device=dev)
+    rstd = torch.empty(B * L, 2 * H, device=dev)
+    rp = (cos.to(dev), sin.to(dev)) if rope else None
+    ops.qk_rmsnorm_rope128_fwd(qkv.to(dev), out, gq.to(dev), gk.to(dev), rstd, H, L, Lout, off, rp)
+    dqkv = torch.empty(B * L, 3 * C, dtype=BF, device=dev)
+    dgq = torch.zeros(128, device=dev); dgk = torch.zeros(128, device=dev)
+    ops.qk_rmsnorm_rope128_bwd(dout.to(dev), qkv.to(dev), dqkv, gq.to(dev), gk.to(dev), rstd, dgq, dgk, H, L, Lout, off, rp)
+
+    x = qkv.double().requires_grad_(True)
+    wq, wk = gq.double().requires_grad_(True), gk.double().requires_grad_(True)
+    q, k, v = [t.view(B, L, H, 128) for t in x.view(B, L, 3, C).unbind(2)]
+    q, k = HO.rms_norm(q, wq), HO.rms_norm(k, wk)
+    if rope:
+        q = torch.cat([HO.rope(q[:, :S_rope], cos.double(), sin.double()), q[:, S_rope:]], 1)
+        k = torch.cat([HO.rope(k[:, :S_rope], cos.double(), sin.double()), k[:, S_rope:]], 1)
+    ref = torch.stack([q.reshape(B, L, C), k.reshape(B, L, C), v.reshape(B, L, C)], 2).reshape(B, L, 3 * C)
+    o3 = out.view(B, Lout, 3 * C)
+    assert _rel(o3[:, off:off + L], ref) < 6e-3
+    untouched = torch.ones(Lout, dtype=torch.bool); untouched[off:off + L] = False
+    assert (o3[:, untouched.to(dev)] == 7.0).all()
+    (ref * dout.double().view(B, Lout, 3 * C)[:, off:off + L]).sum().backward()
+    assert _rel(dqkv, x.grad) < 8e-3
+    assert _rel(dgq, wq.grad) < 5e-3 and _rel(dgk, wk.grad) < 5e-3
+
+
+def _golden():
+    g = np.load(os.path.join(G, "hunyuan_blocks.npz"))
+    return g, (lambda k: torch.from_numpy(g[k]))
+
+
+def _blocks(dev, n_double, n_single, seed, fp8=False):
+    import hunyuan_oracle as HO
+    from vt355.hunyuan import HunyuanBlocks
+    m = HunyuanBlocks(hidden_size=256, heads_num=2, mm_double_blocks_depth=n_double, mm_single_blocks_depth=n_single, fp8=fp8)
+    pre = "double_blocks.0." if n_double else "single_blocks.0."
+    shapes = HO.double_block_shapes(256, 2, pre=pre) if n_double else HO.single_block_shapes(256, 2, pre=pre)
+    P = HO.init(shapes, seed)
+    assert sorted(P) == sorted(k for k, _ in m.named_parameters())
+    m.load_state_dict(P, strict=False)
+    m.to(dev)
+    Pr = {k: v.detach().float().cpu().double().requires_grad_(True) for k, v in m.named_parameters()}
+    return HO, m, Pr, pre
+
+
+def _check_param_grads(m, ts, Pr, tag):
+    bad, tn, td, worst = [], 0.0, 0.0, 0.0
+    for n in m.shapes:
+        gd = m._view(ts.grad, n).detach().double().cpu()
+        gr = Pr[n].grad
+        e, d = (gd - gr).norm().item(), gr.norm().item()
+        tn += e * e; td += d * d
+        cos = torch.nn.functional.cosine_similarity(gd.flatten(), gr.flatten(), dim=0).item()
+        worst = max(worst, e / max(d, 1e-12))
+        if cos < 0.985 or e / max(d, 1e-12) > 0.15:
+            bad.append((n, e / max(d, 1e-12), cos))
+    print(f"[hunyuan {tag}] parameter grads: overall rel-L2 {(tn / td) ** 0.5:.3e}, worst {worst:.3e}")
+    assert not bad, bad[:8]
+
+
+def test_double_block_train_step_matches_oracle(dev):
+    """one MMDoubleStreamBlock, forward + every gradient (img, txt, vec, all 24 parameters), on the golden's inputs (text lengths 12 and 7
+    of 12), vs the fp64 oracle run on the same bf16-rounded weights and inputs"""
+    g, T = _golden()
+    HO, m, Pr, pre = _blocks(dev, 1, 0, seed=1)
+    ts = m.enable_training()
+    tv = T("txt_valid")
+    img, txt, vec = [T(k).to(BF) for k in ("img", "txt", "vec")]
+    Li, Lt = img.shape[1], txt.shape[1]
+    xi, xt, xv = [t.to(dev).requires_grad_(True) for t in (img, txt, vec)]
+    out = m(xi, xt, xv, tv.to(dev), (T("cos").to(dev), T("sin").to(dev)))
+    gi, gt = T("d_gi").to(BF), T("d_gt").to(BF)                       # zero on the padding text rows
+    out.backward(torch.cat([gi, gt], 1).to(dev))
+    ri, rt, rv = [t.double().requires_grad_(True) for t in (img, txt, vec)]
+    io, to = HO.double_block(ri, rt, rv, Pr, pre, 2, tv, T("cos").double(), T("sin").double())
+    ((io * gi.double()).sum() + (to * gt.double()).sum()).backward()
+    valid = (gt.abs().sum(-1, keepdim=True) > 0).double()
+    e_img, e_txt = _rel(out[:, :Li], io), _rel(out[:, Li:].double().cpu() * valid, to * valid)
+    print(f"[hunyuan double] fwd rel-L2 img {e_img:.3e} txt {e_txt:.3e}; vs reference golden img {_rel(out[:, :Li], T('d_img')):.3e}")
+    assert e_img < 1e-2 and e_txt < 1e-2 and _rel(out[:, :Li], T("d_img")) < 2e-2
+    for name, got, ref in (("dimg", xi.grad, ri.grad), ("dtxt", xt.grad, rt.grad), ("dvec", xv.grad, rv.grad)):
+        e = _rel(got, ref)
+        print(f"[hunyuan double] {name} rel-L2 {e:.3e}")
+        assert e < 3e-2, name
+    _check_param_grads(m, ts, Pr, "double")
+
+
+def test_single_block_train_step_matches_oracle(dev):
+    g, T = _golden()
+    HO, m, Pr, pre = _blocks(dev, 0, 1, seed=2)
+    ts = m.enable_training()
+    tv = T("txt_valid")
+    img, txt, vec = [T(k).to(BF) for k in ("img", "txt", "vec")]
+    Li, Lt = img.shape[1], txt.shape[1]
+    xi, xt, xv = [t.to(dev).requires_grad_(True) for t in (img, txt, vec)]
+    out = m(xi, xt, xv, tv.to(dev), (T("cos").to(dev), T("sin").to(dev)))
+    gx = T("s_gx").to(BF)
+    out.backward(gx.to(dev))
+    rx = torch.cat([img, txt], 1).double().requires_grad_(True)
+    rv = vec.double().requires_grad_(True)
+    xo = HO.single_block(rx, rv, Pr, pre, 2, Lt, tv, T("cos").double(), T("sin").double())
+    (xo * gx.double()).sum().backward()
+    vm = (gx.abs().sum(-1, keepdim=True) > 0).double()
+    e = _rel(out.double().cpu() * vm, xo * vm)
+    e_ref = _rel(out.double().cpu() * vm, T("s_x").double() * vm)
+    print(f"[hunyuan single] fwd rel-L2 {e:.3e}; vs reference golden {e_ref:.3e}")
+    assert e < 1e-2 and e_ref < 2e-2
+    dx = torch.cat([xi.grad, xt.grad], 1)
+    assert _rel(dx, rx.grad) < 3e-2 and _rel(xv.grad, rv.grad) < 3e-2
+    _check_param_grads(m, ts, Pr, "single")
+
+
+def test_double_then_single_stack_and_fp8_projection(dev):
+    """2 double + 2 single blocks: the stack runs forward / backward / optimizer step; with fp8=True (qkv projections on the fp8 matrix
+    cores, per-tensor E4M3 scales) the output stays within fp8 rounding of the bf16 run"""
+    from vt355.hunyuan import HunyuanBlocks, flow_matching_loss
+    from vt355.optim import FusedAdamW
+    gen = torch.Generator().manual_seed(9)
+    B, Li, Lt, D = 2, 48, 16, 256
+    img, txt, vec = torch.randn(B, Li, D, generator=gen).to(BF), torch.randn(B, Lt, D, generator=gen).to(BF), torch.randn(B, D, generator=gen).to(BF)
+    tv = torch.tensor([16, 5])
+    cos, sin = _rope_tables(Li, gen)
+    outs = {}
+    for fp8 in (False, True):
+        m = HunyuanBlocks(hidden_size=D, heads_num=2, mm_double_blocks_depth=2, mm_single_blocks_depth=2, fp8=fp8).to(dev).init_weights(4)
+        ts = m.enable_training()
+        out = m(img.to(dev), txt.to(dev), vec.to(dev), tv.to(dev), (cos.to(dev), sin.to(dev)))
+        outs[fp8] = out[:, :Li].float()
+        x0, noise = torch.randn(B, Li, D, generator=gen).to(dev), torch.randn(B, Li, D, generator=gen).to(dev)
+        loss, dpred = flow_matching_loss(out[:, :Li].contiguous(), x0, noise)
+        ref = ((out[:, :Li].float() - (noise - x0)) ** 2).mean()
+        assert abs(loss.item() - ref.item()) < 1e-4 * ref.item()
+        dfull = torch.zeros_like(out); dfull[:, :Li] = dpred
+        out.backward(dfull)
+        assert torch.isfinite(ts.grad).all() and ts.grad.abs().max().item() > 0
+        opt = FusedAdamW(ts.params, lr=1e-3, fullft_state=ts)
+        before = ts.flat.clone()
+        opt.step()
+        assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
+    e = _rel(outs[True], outs[False])
+    print(f"[hunyuan fp8] image rows, fp8 qkv projections vs bf16: rel-L2 {e:.3e}")
+    assert 0 < e < 6e-2

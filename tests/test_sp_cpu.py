@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the Ulysses exchange of vt355.sp around a dense torch attention core -- the sharded joint [image; text]
+attention (forward and gradients) equals the single-process one.  The reference's counterpart is xfuser's xFuserLongContextAttention
+with joint_strategy="rear" (hyvideo_t2v/modules/attenion.py:157-215), a dependency that is not in this image: parity unpinned against
+xfuser itself, pinned against the unsharded attention the reference runs when ulysses_degree == 1."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dense_core(q, k, v, kv_len):
+    """[B, S, h, d] attention with keys >= kv_len[b] masked"""
+    B, S, h, d = q.shape
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * d ** -0.5
+    if kv_len is not None:
+        dead = torch.arange(S)[None, :] >= kv_len[:, None]
+        s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    return torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(11)
+    B, Li, Lt, H, d = 2, 12, 5, 4, 8
+    t = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    img = [t(B, Li, H, d) for _ in range(3)]
+    txt = [t(B, Lt, H, d) for _ in range(3)]
+    gi, gt = t(B, Li, H, d), t(B, Lt, H, d)
+    tv = torch.tensor([5, 2])
+    gt[1, 2:] = 0                                            # padding text rows carry no gradient
+    return img, txt, gi, gt, tv, Li
+
+
+def _reference():
+    img, txt, gi, gt, tv, Li = _inputs()
+    leaves = [x.clone().requires_grad_(True) for x in img + txt]
+    q, k, v = (torch.cat([leaves[i], leaves[3 + i]], 1) for i in range(3))
+    out = _dense_core(q, k, v, tv + Li)
+    ((out[:, :Li] * gi).sum() + (out[:, Li:] * gt).sum()).backward()
+    return out.detach(), [x.grad for x in leaves]
+
+
+def _worker(rank, world, port, res):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vt355 import sp
+    img, txt, gi, gt, tv, Li = _inputs()
+    n = Li // world
+    sl = slice(rank * n, (rank + 1) * n)
+    li = [x[:, sl].clone().requires_grad_(True) for x in img]
+    lt = [x.clone().requires_grad_(True) for x in txt]
+    oi, ot = sp.ulysses_joint_attention(_dense_core, *li, *lt, txt_valid=tv)
+    # the loss: image rows sharded (each rank its own), text rows replicated (the replicated-full convention: every rank back-propagates
+    # the same text gradient)
+    ((oi * gi[:, sl]).sum() + (ot * gt).sum()).backward()
+    res[rank] = (oi.detach(), ot.detach(), [x.grad for x in li], [x.grad for x in lt])
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_ulysses_joint_attention_world2_matches_unsharded():
+    mgr = mp.Manager(); res = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), res), nprocs=2, join=True)
+    out, grads = _reference()
+    Li = 12
+    oi = torch.cat([res[0][0], res[1][0]], 1)
+    assert torch.allclose(oi, out[:, :Li], atol=1e-12)
+    valid = torch.ones(2, 5, dtype=torch.bool); valid[1, 2:] = False
+    for r in (0, 1):
+        assert torch.allclose(res[r][1][valid], out[:, Li:][valid], atol=1e-12)            # text output replicated on both ranks
+    for i in range(3):
+        gi = torch.cat([res[0][2][i], res[1][2][i]], 1)
+        assert torch.allclose(gi, grads[i], atol=1e-12), ("image operand", i)
+        for r in (0, 1):                                                                   # text gradients: complete on every rank
+            assert torch.allclose(res[r][3][i], grads[3 + i], atol=1e-12), ("text operand", i, r)
+
+
+def test_single_rank_group_is_plain_attention():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from vt355 import sp
+        img, txt, gi, gt, tv, Li = _inputs()
+        oi, ot = sp.ulysses_joint_attention(_dense_core, *img, *txt, txt_valid=tv)
+        out, _ = _reference()
+        assert torch.allclose(oi, out[:, :Li]) and torch.allclose(ot[0], out[0, Li:])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_core_refuses_cpu():
+    from vt355 import sp
+    import pytest
+    q = torch.zeros(1, 4, 2, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        sp.device_core(q, q, q, None)

@@ -816,3 +816,22 @@ def gemm_fp8(aq, wq, out, scale_a, scale_w, bias=None):
     check(load_library().vt_gemm_fp8(aq.data_ptr(), aq.stride(0), wq.data_ptr(), wq.stride(0), out.data_ptr(), out.stride(0), aq.shape[0],
                                      wq.shape[0], aq.shape[1], _p(bias), scale_a.data_ptr(), scale_w.data_ptr(), _stream()), "vt_gemm_fp8")
     return out
+
+
+def qk_rmsnorm_rope128_fwd(qkv, out, gq, gk, rstd, H: int, L: int, Lout: int, row_off: int, rope=None, eps: float = 1e-6):
+    """qkv bf16 [M, 3*H*128] -> out rows (m // L) * Lout + row_off + m % L: q^ | k^ | v.  rope = (cos, sin) fp32 [S_rope, 128] for the
+    first S_rope positions of every sample"""
+    _req(qkv, BF16, "qkv", 2); _req(out, BF16, "out", 2)
+    cos, sin = (None, None) if rope is None else rope
+    check(load_library().vt_qk_rmsnorm_rope128_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), gk.data_ptr(),
+                                                   rstd.data_ptr(), _p(cos), _p(sin), qkv.shape[0], H, L, Lout, row_off,
+                                                   0 if cos is None else cos.shape[0], eps, _stream()), "vt_qk_rmsnorm_rope128_fwd")
+
+
+def qk_rmsnorm_rope128_bwd(dout, qkv, dqkv, gq, gk, rstd, dgq, dgk, H: int, L: int, Lout: int, row_off: int, rope=None):
+    _req(dout, BF16, "dout", 2); _req(qkv, BF16, "qkv", 2); _req(dqkv, BF16, "dqkv", 2)
+    cos, sin = (None, None) if rope is None else rope
+    check(load_library().vt_qk_rmsnorm_rope128_bwd(dout.data_ptr(), dout.stride(0), qkv.data_ptr(), qkv.stride(0), dqkv.data_ptr(), dqkv.stride(0),
+                                                   gq.data_ptr(), gk.data_ptr(), rstd.data_ptr(), _p(cos), _p(sin), dgq.data_ptr(), dgk.data_ptr(),
+                                                   qkv.shape[0], H, L, Lout, row_off, 0 if cos is None else cos.shape[0], _stream()),
+          "vt_qk_rmsnorm_rope128_bwd")

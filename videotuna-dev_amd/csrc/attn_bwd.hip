@@ -88,6 +88,25 @@
 #ifndef VT_ABL
 #define VT_ABL 0      // timing-only ablations (results are WRONG): 1 = no dQ phase, 2 = no dQ atomics, 3 = no exp2, 4 = no dS image write, 5 = no row-constant reads, 6 = no transposed Q / dO reads, 7 = 5 + 6 (5..7: eight-wave body)
 #endif
+#ifndef VT_PF
+#define VT_PF 1       // 1 = software-pipelined S phase with the issue order pinned by sched_barrier fences: all operand reads of a segment are
+#endif                // in flight before its MFMAs, the next segment's reads are issued between the current segment's MFMAs
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef DQ_RING
+#define DQ_RING 4
+#endif
+#ifndef VT_DQ2
+#define VT_DQ2 0
+#endif
+#ifndef PF_TRN
+#define PF_TRN 2      // transposed-operand pairs of a dV / dK segment in flight before its first MFMA (2: two-deep ring refilled inside the segment)
+#endif
+#ifndef PF_R0
+#define PF_R0 0       // 1 = the first reads of a step are issued right after the previous step's barrier
+#endif
+#ifndef VT_STAMP
+#define VT_STAMP 0    // 1 = instrumentation build (tools/build_variants.sh): s_memtime stamps of one step of one workgroup, read back with
+#endif                // vt_attn_bwd_stamps<suffix>; the stamps order memory operations around them, so the build is slower than the shipped one
 #define VT_CAT_(a, b) a##b
 #define VT_CAT(a, b) VT_CAT_(a, b)
 #define BWD_KERNEL VT_CAT(attn_bwd_hd64_kernel, VT_SUFFIX)
@@ -125,7 +144,18 @@ struct AttnBwdParams {
 #ifndef BWD_LDS_PAD
 #define BWD_LDS_PAD 0
 #endif
-#define BWD_LDS (132096 + (VT_STATMFMA ? 8192 : BWD_LDS_PAD))
+#define BWD_LDS (132096 + (VT_STATMFMA ? 8192 : (VT_STAMP ? 1024 : BWD_LDS_PAD)))
+#if VT_STAMP
+#ifndef STAMP_SLOT
+#define STAMP_SLOT 40
+#endif
+#define STAMP_STEP 150
+__device__ unsigned VT_CAT(vt_bwd_stamps, VT_SUFFIX)[256];
+#define STAMP(i, dep) do { if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(dep) :: "memory"); \
+                                      if (lane == 0) ((unsigned*)(smem + 132096))[w * 16 + (i)] = (unsigned)t_; } } while (0)
+#else
+#define STAMP(i, dep)
+#endif
 #define CH_STAGE_BYTES 16384     // incoming dQ tile of the chain predecessor: 4 waves x 4 KiB, a separate LDS object so
                                  // that the compiler does not order every ds_read of a step behind the DMA that fills it
 #ifndef CH_R
@@ -325,35 +355,144 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     lstore(0);
     __syncthreads();
     int s_ready = (has_prod && dqw) ? __builtin_amdgcn_readfirstlane(pf_ready) : 0;
-    for (int t = 0; t < nsteps; ++t) {
-        const int buf = t & 1;
-        int pf_cons = 0;
-        if (has_prod && dqw) {
-            if (s_ready < base + t + 1)
-                fl_wait(fl_ready_prod, base + (t + 1 + CH_HYST < nsteps ? t + 1 + CH_HYST : nsteps), s_ready, spins_r);
-            // hidden LDS-DMA of the predecessor's tile t (see the four-wave body for why it goes through inline asm)
+    // everything step t1 fetches from memory: the chain predecessor's dQ tile t1 (LDS-DMA into the stage), the counter for t1 + 1, the
+    // Q / dO tile t1 + 1.  Shipped order: at the top of step t1.  VT_PF: right after the barrier of step t1 - 1, BEFORE that step's dQ
+    // atomics -- vector-memory instructions issue in order, and the loads of a wave that has just pushed 16 atomics (16 B/clk per CU)
+    // waited ~500-700 cycles for their turn (profiles/r02_attn_bwd_stamps_before_L2_consumer.txt, "loads issued")
+    auto prefetch = [&](int t1) {
+        if (has_prod && dqw && t1 < nsteps) {
+            if (s_ready < base + t1 + 1)
+                fl_wait(fl_ready_prod, base + (t1 + 1 + CH_HYST < nsteps ? t1 + 1 + CH_HYST : nsteps), s_ready, spins_r);
+            // hidden LDS-DMA of the predecessor's tile t1 (see the four-wave body for why it goes through inline asm)
             if (l2_prev) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
                                  :: "s"(stage_lds + wu * WTILE + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
-                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+                                    "s"(((base + t1) % CH_R) * 16384) : "memory");
             } else {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds"
                                  :: "s"(stage_lds + wu * WTILE + j * 1024), "v"(tile_voff + j * 1024), "s"(rt_prod_w),
-                                    "s"(((base + t) % CH_R) * 16384) : "memory");
+                                    "s"(((base + t1) % CH_R) * 16384) : "memory");
             }
             pf_ready = fl_load(fl_ready_prod);
         }
+        gload(t1 + 1);                                 // past the end: bounds-checked loads return zeros
+    };
+#if VT_PF
+    prefetch(0);
+    // S'' / dP' of q-half 0 (initialised with the row constants) and the two-deep ring of Q / dO row operands are carried from step to
+    // step: the first reads of step t + 1 are issued right after the barrier of step t, before anything else
+    f32x16 sacc[2], pacc[2];
+    bf16x8 qa[2], doa[2];
+    auto rd_init = [&](const float* lsel_, int qs, int g0, int g1) {
+#pragma unroll
+        for (int gg = g0; gg < g1; ++gg) {
+            const f32x4 a = *(const f32x4*)(lsel_ + 32 * qs + 8 * gg + 4 * h);
+            const f32x4 c = *(const f32x4*)(lsel_ + 64 + 32 * qs + 8 * gg + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sacc[qs][4 * gg + e] = RAGGED ? a[e] + kmask : a[e]; pacc[qs][4 * gg + e] = c[e]; }
+        }
+    };
+    auto rd_rows = [&](const char* qimg_, const char* doimg_, int qs, int s_) {
+        qa[s_ & 1] = *(const bf16x8*)(qimg_ + qs * 4096 + rowrd[s_]);
+        doa[s_ & 1] = *(const bf16x8*)(doimg_ + qs * 4096 + rowrd[s_]);
+    };
+    auto rd_first = [&](int bufn) {
+        const char* qn = smem + QTILE + bufn * 16384;
+        rd_init((const float*)(smem + LSEOFF + bufn * 512), 0, 0, 4);
+        rd_rows(qn, qn + 8192, 0, 0); rd_rows(qn, qn + 8192, 0, 1);
+        FENCE();
+    };
+#if PF_R0
+    rd_first(0);
+#endif
+#endif
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        int pf_cons = 0;
+#if VT_STAMP
+        const bool rec = slot == STAMP_SLOT && t == STAMP_STEP && base == 0;
+        int stamp_dummy = 0;
+        STAMP(0, stamp_dummy);
+#endif
+#if !VT_PF
+        prefetch(t);
+#endif
         if (has_cons && dqw) pf_cons = fl_load(fl_cons_next);
-        gload(t + 1);                                  // past the end: bounds-checked loads return zeros
         const char* qimg = smem + QTILE + buf * 16384;
         const char* doimg = qimg + 8192;
         const float* lsel = (const float*)(smem + LSEOFF + buf * 512);
         char* dsimg = smem + DSIMG + buf * 32768;
+        STAMP(1, stamp_dummy);
 
+#if VT_PF
+        {
+            // The compiler's own order issues every operand read right before the MFMA that needs it (one LDS round trip exposed per
+            // k-step: profiles/r02_attn_bwd_stamps_before_*.txt -- 650-950 cycles per 8-MFMA segment against 256 of matrix-pipe time).
+            // Here: segment = 8 MFMAs; its reads are issued during the previous segment (q-half 0's first ones right after the previous
+            // step's barrier, below), fences keep the compiler from sinking them.
+            bf16x8 doT[PF_TRN], qT[PF_TRN];
+            unsigned pw[8], dw[8];
+            auto rd_tr = [&](int qs, int j) {          // pair j = (s2, dt) = (j >> 1, j & 1)
+                const int ro = (32 * qs + 16 * (j >> 1)) * 128, dt = j & 1;
+                doT[j % PF_TRN] = tr_pair(doimg + ro + trA[dt][0], doimg + ro + trA[dt][1]);
+                qT[j % PF_TRN] = tr_pair(qimg + ro + trA[dt][0], qimg + ro + trA[dt][1]);
+            };
+#if !PF_R0
+            rd_first(buf);
+#endif
+            FENCE();
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    sacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s_ & 1], kf[s_], sacc[qs], 0, 0, 0);
+                    pacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[s_ & 1], vf[s_], pacc[qs], 0, 0, 0);
+                    if (s_ < 2) rd_rows(qimg, doimg, qs, s_ + 2); else rd_tr(qs, s_ - 2);       // into the slot these MFMAs just read
+                    FENCE();
+                }
+#if PF_TRN == 4
+                rd_tr(qs, 2); rd_tr(qs, 3);             // land under the exp2 block
+                FENCE();
+#endif
+                STAMP(2 + 3 * qs, pacc[qs][15]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? sacc[qs][2 * i] : sacc[qs][2 * i] * sc);
+                    const float p1 = __builtin_amdgcn_exp2f(PRESCALED ? sacc[qs][2 * i + 1] : sacc[qs][2 * i + 1] * sc);
+                    pw[i] = pack2(p0, p1);
+                    dw[i] = pack2(p0 * pacc[qs][2 * i], p1 * pacc[qs][2 * i + 1]);
+                }
+                STAMP(3 + 3 * qs, dw[7]);
+                FENCE();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s2 = j >> 1, dt = j & 1;
+                    const u32x4 pb4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+                    const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+                    dv_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[j % PF_TRN], __builtin_bit_cast(bf16x8, pb4), dv_acc[dt], 0, 0, 0);
+                    dk_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[j % PF_TRN], __builtin_bit_cast(bf16x8, db4), dk_acc[dt], 0, 0, 0);
+                    if (PF_TRN == 2 && j < 2) rd_tr(qs, j + 2);
+                    if (qs == 0) {                      // the other q-half's first reads ride under these MFMAs
+                        rd_init(lsel, 1, j, j + 1);
+                        if (j >= 2) rd_rows(qimg, doimg, 1, j - 2);
+                    }
+                    FENCE();
+                }
+                char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
+                    *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+                }
+                STAMP(4 + 3 * qs, dk_acc[1][15]);
+                FENCE();
+            }
+        }
+#else
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             // S'' and dP' accumulators start from the row constants (-lse2/c [+ key mask], -delta)
@@ -378,6 +517,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             }
             // P = exp2(c * S''), dS = P * dP'; both packed to bf16 pairs (B operands + dS image)
             unsigned pw[8], dw[8];
+            STAMP(2 + 3 * qs, pacc[15]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? sacc[2 * i] : sacc[2 * i] * sc);
@@ -385,6 +525,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 pw[i] = pack2(p0, p1);
                 dw[i] = pack2(p0 * pacc[2 * i], p1 * pacc[2 * i + 1]);
             }
+            STAMP(3 + 3 * qs, dw[7]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const u32x4 pb4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
@@ -411,9 +552,16 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
                 *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
             }
+            STAMP(4 + 3 * qs, dk_acc[1][15]);
         }
+#endif
         lstore(buf ^ 1);
+        STAMP(8, stamp_dummy);
         __syncthreads();
+        STAMP(9, stamp_dummy);
+#if VT_PF && PF_R0
+        rd_first(buf ^ 1);
+#endif
 
 #if VT_DQ16
         // ---- dQ: two 16x16 tiles per wave over all 256 keys (all eight waves) ----
@@ -426,6 +574,14 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 if (has_prod) dq16[j] = *(const f32x4*)(stage + wu * WTILE + j * 1024 + lane * 16);
                 else dq16[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+#if VT_PF
+            if (has_prod) __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (has_cons && t > 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t), rfl, fl_ready_me, 0, CH_AUX);
+            }
+            prefetch(t + 1);
+#endif
 #pragma unroll
             for (int s3 = 0; s3 < 8; ++s3) {
                 const bf16x8 fa = tr_pair(dsimg + s3 * 4096 + trq16[0], dsimg + s3 * 4096 + trq16[1]);
@@ -440,10 +596,12 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 int need = a - CH_R + 1;
                 if (t < CH_R && need > cons_end) need = cons_end;
                 if (need > 0) fl_wait(fl_cons_next, need, s_cons, spins_c);
+#if !VT_PF
                 if (t > 0) {
                     __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): tile t-1 is a step old
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned)a, rfl, fl_ready_me, 0, CH_AUX);
                 }
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (l2_next)
@@ -473,6 +631,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     }
 #else
         // ---- dQ tile (32 q x 32 d) over all 256 keys: waves 0..3 only; waves 4..7 go on with the next step ----
+#if VT_PF
+        if (!dqw) prefetch(t + 1);
+#endif
         if (dqw) {
 #if VT_DQPRIO
             __builtin_amdgcn_s_setprio(3);         // the step barrier waits for these waves: let them win the issue arbitration
@@ -491,21 +652,64 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
             }
+#if VT_PF
+            if (has_prod) __builtin_amdgcn_s_waitcnt(0xc07f);                             // the stage has been read: the next DMA may land
+            if (has_cons && t > 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0): tile t-1 is a step old
+                __builtin_amdgcn_raw_buffer_store_b32((unsigned)(base + t), rfl, fl_ready_me, 0, CH_AUX);
+            }
+            prefetch(t + 1);
+#endif
+#if VT_PF
+            {
+                bf16x8 fa[DQ_RING], fb[DQ_RING];              // DQ_RING k-steps of operands in flight (the compiler's order: one, waited for at once)
+                auto rd_dq = [&](int s3) {
+                    fa[s3 % DQ_RING] = tr_pair(dsimg + s3 * 2048 + trQA[0], dsimg + s3 * 2048 + trQA[1]);
+                    fb[s3 % DQ_RING] = tr_pair(smem + KIMG + s3 * 2048 + trQB[0], smem + KIMG + s3 * 2048 + trQB[1]);
+                };
+#pragma unroll
+                for (int s3 = 0; s3 < DQ_RING; ++s3) rd_dq(s3);
+                FENCE();
+#if VT_DQ2
+                f32x16 dq_odd;                    // two accumulation chains: a dependent MFMA waits for its predecessor's last pass
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dq_odd[i] = 0.f;
+#endif
+#pragma unroll
+                for (int s3 = 0; s3 < 16; ++s3) {
+#if VT_DQ2
+                    if (s3 & 1) dq_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s3 % DQ_RING], fb[s3 % DQ_RING], dq_odd, 0, 0, 0);
+                    else
+#endif
+                    dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s3 % DQ_RING], fb[s3 % DQ_RING], dq_acc, 0, 0, 0);
+                    if (s3 + DQ_RING < 16) rd_dq(s3 + DQ_RING);
+                    FENCE();
+                }
+#if VT_DQ2
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dq_acc[i] += dq_odd[i];
+#endif
+            }
+#else
 #pragma unroll
             for (int s3 = 0; s3 < 16; ++s3) {
                 const bf16x8 fa = tr_pair(dsimg + s3 * 2048 + trQA[0], dsimg + s3 * 2048 + trQA[1]);
                 const bf16x8 fb = tr_pair(smem + KIMG + s3 * 2048 + trQB[0], smem + KIMG + s3 * 2048 + trQB[1]);
                 dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, dq_acc, 0, 0, 0);
             }
+#endif
+            STAMP(10, dq_acc[15]);
             if (has_cons) {
                 const int a = base + t;
                 int need = a - CH_R + 1;
                 if (t < CH_R && need > cons_end) need = cons_end;
                 if (need > 0) fl_wait(fl_cons_next, need, s_cons, spins_c);
+#if !VT_PF
                 if (t > 0) {
                     __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): tile t-1 is a step old
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned)a, rfl, fl_ready_me, 0, CH_AUX);
                 }
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 v = {dq_acc[4 * j], dq_acc[4 * j + 1], dq_acc[4 * j + 2], dq_acc[4 * j + 3]};
@@ -531,7 +735,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #if VT_DQPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
+            STAMP(11, stamp_dummy);
         }
+    }
+#endif
+#if VT_STAMP
+    if (slot == STAMP_SLOT && base == 0) {
+        __syncthreads();
+        if (tid < 128) VT_CAT(vt_bwd_stamps, VT_SUFFIX)[tid] = ((const unsigned*)(smem + 132096))[tid];
+        if (tid == 0) { VT_CAT(vt_bwd_stamps, VT_SUFFIX)[128] = (unsigned)ROLE; VT_CAT(vt_bwd_stamps, VT_SUFFIX)[129] = (unsigned)id; }
     }
 #endif
     if (dqw) {
@@ -1423,6 +1635,11 @@ extern "C" int BWD_ENTRY(const void* q, const void* k, const void* v, const void
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 
+#if VT_STAMP
+extern "C" int VT_CAT(vt_attn_bwd_stamps, VT_SUFFIX)(unsigned* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(VT_CAT(vt_bwd_stamps, VT_SUFFIX)), 256 * sizeof(unsigned)) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+#endif
 // bytes of chain workspace vt_attn_bwd_hd64 wants for this problem (0: chains are disabled on this device / by VT_BWD_CHAIN=1)
 extern "C" long long VT_CAT(vt_attn_bwd_chain_ws_bytes, VT_SUFFIX)(int B, int H, int S) {
     if (B <= 0 || H <= 0 || S <= 0 || bwd_chain_len() <= 1) return 0;

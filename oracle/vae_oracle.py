@@ -60,10 +60,23 @@ def causal_conv3d(x, w, b):
     return F.conv3d(x, w, b)
 
 
-def resnet_block(x, P, pre, cin, cout):
-    h = F.group_norm(x, 32, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-6)
+def group_norm(x, w, b, frame_batch=None, t_in=0):
+    """GroupNorm(32, eps 1e-6) over the whole clip (the in-tree twin; frame_batch None), or with the statistics of every frame batch of
+    diffusers 0.32.2 AutoencoderKLCogVideoX._encode (frame_batch 8: first batch 8 + 1 frames, then 8 at a time; restated from the
+    published source of a dependency that is not in this image -- parity unpinned for this mode)"""
+    T = x.shape[2]
+    stride = max(1, (t_in - 1) // max(T - 1, 1)) if T > 1 else 1
+    if frame_batch is None or t_in <= frame_batch + 1 or (t_in - 1) % frame_batch or frame_batch % stride:
+        return F.group_norm(x, 32, w, b, 1e-6)
+    first, rest = frame_batch // stride + 1, frame_batch // stride
+    parts = [x[:, :, :first]] + list(torch.split(x[:, :, first:], rest, dim=2))
+    return torch.cat([F.group_norm(p_, 32, w, b, 1e-6) for p_ in parts], dim=2)
+
+
+def resnet_block(x, P, pre, cin, cout, frame_batch=None, t_in=0):
+    h = group_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], frame_batch, t_in)
     h = causal_conv3d(swish(h), P[pre + "conv1.conv.weight"], P[pre + "conv1.conv.bias"])
-    h = F.group_norm(h, 32, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-6)
+    h = group_norm(h, P[pre + "norm2.weight"], P[pre + "norm2.bias"], frame_batch, t_in)
     h = causal_conv3d(swish(h), P[pre + "conv2.conv.weight"], P[pre + "conv2.conv.bias"])
     if cin != cout:
         x = F.conv3d(x, P[pre + "nin_shortcut.weight"], P[pre + "nin_shortcut.bias"])
@@ -135,21 +148,22 @@ def init_params(cfg: VaeEncConfig, seed: int = 0, dtype=torch.float32) -> Dict[s
     return {k: v.to(dtype) for k, v in P.items()}
 
 
-def encoder_forward(P: Dict[str, torch.Tensor], cfg: VaeEncConfig, x: torch.Tensor) -> torch.Tensor:
+def encoder_forward(P: Dict[str, torch.Tensor], cfg: VaeEncConfig, x: torch.Tensor, frame_batch=None) -> torch.Tensor:
     """x [B, 3, T, H, W] -> moments [B, 2 * z_channels, T', H / 2^(L-1), W / 2^(L-1)]"""
     import math
+    t_in = x.shape[2]
     tlevels = int(math.log2(cfg.temporal_compress_times))
     h = causal_conv3d(x, P["conv_in.conv.weight"], P["conv_in.conv.bias"])
     chans = level_channels(cfg)
     for i, (cin, cout) in enumerate(chans):
         for j in range(cfg.num_res_blocks):
-            h = resnet_block(h, P, f"down.{i}.block.{j}.", cin if j == 0 else cout, cout)
+            h = resnet_block(h, P, f"down.{i}.block.{j}.", cin if j == 0 else cout, cout, frame_batch, t_in)
         if i != len(chans) - 1:
             h = downsample(h, P, f"down.{i}.downsample.", i < tlevels)
     top = chans[-1][1]
-    h = resnet_block(h, P, "mid.block_1.", top, top)
-    h = resnet_block(h, P, "mid.block_2.", top, top)
-    h = F.group_norm(h, 32, P["norm_out.weight"], P["norm_out.bias"], 1e-6)
+    h = resnet_block(h, P, "mid.block_1.", top, top, frame_batch, t_in)
+    h = resnet_block(h, P, "mid.block_2.", top, top, frame_batch, t_in)
+    h = group_norm(h, P["norm_out.weight"], P["norm_out.bias"], frame_batch, t_in)
     return causal_conv3d(swish(h), P["conv_out.conv.weight"], P["conv_out.conv.bias"])
 
 

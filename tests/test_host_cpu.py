@@ -455,3 +455,33 @@ def test_videocrafter2_and_opensora_yaml_files_load_unchanged():
     n = sum(p.numel() for p in m.parameters())
     assert abs(n - 759.6e6) < 0.5e6, n
     assert callable(osr.configure_optimizers) and osr.scheduler.num_timesteps == 1000
+
+
+def test_encoding_cache_hits_and_resampling():
+    """vt355.prefetch.EncodingCache: prompt embeddings by caption (the encoder runs once per distinct caption), latent moments by index
+    (the posterior runs once per index, every hit re-draws the sample), byte bound evicts the oldest entries"""
+    from types import SimpleNamespace
+    from vt355.prefetch import EncodingCache
+    calls = {"text": [], "vae": 0}
+
+    def enc(caps):
+        calls["text"].append(list(caps))
+        return torch.stack([torch.full((4, 8), float(len(c))) for c in caps])
+
+    def post(v):
+        calls["vae"] += 1
+        return SimpleNamespace(mean=v[:, :2] * 0 + 3.0, std=v[:, :2] * 0 + 0.5)
+
+    ec = EncodingCache()
+    e1 = ec.prompt_embeds(["a", "bb", "a"], enc)
+    e2 = ec.prompt_embeds(["bb", "ccc"], enc)
+    assert calls["text"] == [["a", "bb"], ["ccc"]] and e1.shape == (3, 4, 8) and torch.equal(e1[0], e1[2]) and e2[1, 0, 0] == 3
+    vids = [torch.zeros(3, 5, 4, 4), torch.zeros(3, 5, 4, 4)]
+    g = torch.Generator().manual_seed(0)
+    l1 = ec.latents([7, 9], vids, post, 0.7, generator=g)
+    l2 = ec.latents(torch.tensor([9, 7]), vids, post, 0.7, generator=g)
+    assert calls["vae"] == 2 and l1.shape == (2, 2, 5, 4, 4) and not torch.equal(l1[0], l2[1])       # same moments, fresh noise
+    assert abs(l2.mean().item() - 3.0 * 0.7) < 0.1 and ec.hits == {"text": 2, "latent": 2}
+    small = EncodingCache(max_bytes=4 * 8 * 4 * 2)
+    small.prompt_embeds(["x", "yy", "zzz"], enc)
+    assert list(small.text) == ["yy", "zzz"]

@@ -177,3 +177,25 @@ def test_double_then_single_stack_and_fp8_projection(dev):
     e = _rel(outs[True], outs[False])
     print(f"[hunyuan fp8] image rows, fp8 qkv projections vs bf16: rel-L2 {e:.3e}")
     assert 0 < e < 6e-2
+
+
+def test_sp_device_core_matches_dense_attention(dev):
+    """vt355.sp.device_core (vt_attn_gen, head_dim 128, per-sample valid lengths) forward and backward vs dense fp64 attention -- the local
+    attention that vt355.sp.ulysses_joint_attention wraps on the device (single rank here: the exchange itself is covered on CPU / gloo)"""
+    from vt355 import sp
+    gen = torch.Generator().manual_seed(3)
+    B, S, h = 2, 200, 3
+    q, k, v, g = [torch.randn(B, S, h, 128, generator=gen).to(BF) for _ in range(4)]
+    kv_len = torch.tensor([200, 137])
+    qd, kd, vd = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out = sp.device_core(qd, kd, vd, kv_len.to(dev))
+    out.backward(g.to(dev))
+    qr, kr, vr = [t.double().requires_grad_(True) for t in (q, k, v)]
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * 128 ** -0.5
+    dead = torch.arange(S)[None, :] >= kv_len[:, None]
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.masked_fill(dead[:, None, None, :], float("-inf")).softmax(-1), vr)
+    ref.backward(g.double())
+    assert _rel(out, ref) < 1e-2
+    for a, b_, n in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+        assert _rel(a, b_) < 2e-2, n
+    assert kd.grad[1, 137:].abs().max().item() == 0 and vd.grad[1, 137:].abs().max().item() == 0

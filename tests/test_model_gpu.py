@@ -376,6 +376,39 @@ def test_full_finetune_loss_curve_tracks_the_oracle(dev):
     assert cr[-1] < 0.99 * cr[0] and cd[-1] < 0.99 * cd[0], (cd, cr)
 
 
+def test_vae_encoder_frame_batches_match_oracle_and_are_causal(dev):
+    """num_sample_frames_batch_size=8 (diffusers' frame batching: GroupNorm statistics per frame batch, 9 frames first) on a tiny encoder:
+    against the oracle's statement of the same rule, and the property that makes it checkable without diffusers -- the first frame
+    batch does not see the later ones: moments of the clip's first 9 frames == the first 3 latent frames of the 25-frame clip"""
+    import vae_oracle as V
+    from vt355.vae import CogVideoXVaeEncoder
+    cfg = V.tiny_config(ch=64)
+    m = CogVideoXVaeEncoder(ch=cfg.ch, ch_mult=cfg.ch_mult, num_res_blocks=cfg.num_res_blocks, z_channels=cfg.z_channels,
+                            temporal_compress_times=cfg.temporal_compress_times, num_sample_frames_batch_size=8).init_weights(3).to(dev)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    x = torch.randn(1, 3, 25, 16, 24, generator=torch.Generator().manual_seed(2)).clamp(-1, 1).to(torch.bfloat16)
+    out = m(x.to(dev)).float().cpu()
+    ref = V.encoder_forward(P, cfg, x.float(), frame_batch=8)
+    whole = V.encoder_forward(P, cfg, x.float())
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 4e-2 and (ref - whole).abs().max().item() > 10 * (out - ref).abs().max().item()      # the two rules really differ
+    head = m(x[:, :, :9].to(dev)).float().cpu()
+    assert (head - out[:, :, :3]).abs().max().item() <= 1e-2 * out.abs().max().item()     # same statistics; GroupNorm's atomic sums move last bits
+
+
+def test_vae_encoder_49_frames_full_resolution_is_causal(dev):
+    """one 49x480x720 clip with frame batching: the first 9-frame window's moments equal the full clip's first 3 latent frames"""
+    from vt355.vae import CogVideoXVaeEncoder
+    m = CogVideoXVaeEncoder(num_sample_frames_batch_size=8).init_weights(1).to(dev)
+    x = torch.randn(1, 3, 49, 480, 720, generator=torch.Generator().manual_seed(4)).clamp(-1, 1).to(torch.bfloat16)
+    full = m(x.to(dev))
+    assert tuple(full.shape) == (1, 32, 13, 60, 90) and torch.isfinite(full.float()).all()
+    head = m(x[:, :, :9].to(dev))
+    d = (head.float() - full[:, :, :3].float()).abs().max().item()
+    print(f"[vae 49x480x720] first window vs full clip: max abs diff {d:.3e} (|moments| max {full.float().abs().max().item():.3f})")
+    assert d <= 2e-2 * full.float().abs().max().item()     # GroupNorm sums are atomic: the last bits depend on the launch shape
+
+
 @pytest.mark.parametrize("T,H,W", [(9, 16, 24), (1, 8, 12), (5, 24, 20)])
 def test_vae_encoder_matches_oracle(dev, T, H, W):
     """The CogVideoX VAE encoder on the vt355 kernels (channels-last implicit-GEMM causal convolutions, GroupNorm+SiLU, temporal pool,

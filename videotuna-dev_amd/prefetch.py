@@ -80,3 +80,59 @@ class EncoderPrefetcher:
                 if t.is_cuda:
                     t.record_stream(main)          # the caching allocator must not recycle them under the side stream
         return out
+
+
+class EncodingCache:
+    """Per-sample cache of what the frozen encoders produce (the reference re-runs the VAE and T5-XXL on every
+    step, cogvideo_pl.py:797-813).  Two stores, both on the device (a 49x480x720 clip is 2.2 MB of latent moments x 2 and 1.9 MB of
+    prompt embedding; 288 GB hold tens of thousands):
+      * prompt embeddings keyed by the caption string -- exact: the text encoder is frozen and deterministic;
+      * latent MOMENTS (mean, std of the VAE posterior) keyed by the batch's optional ``"index"`` entry -- the sample is re-drawn on
+        every hit, so the step sees the same distribution as the reference's ``latent_dist.sample()``; only valid when the loader
+        applies no random crop / frame jitter to that index, hence opt-in by providing the key.
+    ``max_bytes`` bounds the store (oldest entries go first)."""
+
+    def __init__(self, max_bytes: int = 64 << 30):
+        self.max_bytes, self.bytes = max_bytes, 0
+        self.text: Dict[str, torch.Tensor] = {}
+        self.moments: Dict[Any, tuple] = {}
+        self.hits = {"text": 0, "latent": 0}
+        self.misses = {"text": 0, "latent": 0}
+
+    def _room(self, n: int):
+        self.bytes += n
+        for store in (self.moments, self.text):
+            while self.bytes > self.max_bytes and store:
+                v = store.pop(next(iter(store)))
+                self.bytes -= sum(t.numel() * t.element_size() for t in (v if isinstance(v, tuple) else (v,)))
+
+    def prompt_embeds(self, captions, encode: Callable[[list], torch.Tensor]) -> torch.Tensor:
+        miss = [c for c in dict.fromkeys(captions) if c not in self.text]
+        self.misses["text"] += len(miss); self.hits["text"] += len(captions) - len(miss)
+        now = {c: self.text[c] for c in captions if c in self.text}
+        if miss:
+            emb = encode(miss)
+            for c, e in zip(miss, emb):
+                e = e.detach().clone()
+                now[c] = e
+                self._room(e.numel() * e.element_size())
+                self.text[c] = e
+        return torch.stack([now[c] for c in captions], 0)
+
+    def latents(self, indices, videos, posterior: Callable[[torch.Tensor], Any], scaling_factor: float, generator=None) -> torch.Tensor:
+        """posterior(video [1,3,T,H,W]) -> object with .mean / .std (vt355.vae.DiagonalGaussianDistribution)"""
+        out = []
+        for i, v in zip(indices, videos):
+            key = int(i)
+            if key not in self.moments:
+                self.misses["latent"] += 1
+                d = posterior(v.unsqueeze(0) if v.dim() == 4 else v)
+                m, sdev = d.mean.detach().clone(), d.std.detach().clone()
+                self._room((m.numel() + sdev.numel()) * m.element_size())
+                self.moments[key] = (m, sdev)
+            else:
+                self.hits["latent"] += 1
+            m, sdev = self.moments[key]
+            eps = torch.randn(m.shape, generator=generator, device=m.device, dtype=m.dtype)
+            out.append((m + sdev * eps) * scaling_factor)
+        return torch.cat(out, 0)

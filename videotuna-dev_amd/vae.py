@@ -88,8 +88,15 @@ class DiagonalGaussianDistribution:
 class CogVideoXVaeEncoder(nn.Module):
     def __init__(self, ch: int = 128, ch_mult: Tuple[int, ...] = (1, 2, 2, 4), num_res_blocks: int = 3, in_channels: int = 3,
                  z_channels: int = 16, double_z: bool = True, temporal_compress_times: int = 4, scaling_factor: float = 1.15258426,
-                 **unused):
+                 num_sample_frames_batch_size: Optional[int] = None, **unused):
         super().__init__()
+        # None: GroupNorm statistics over the whole clip -- the in-tree twin (ContextParallelGroupNorm gathers every rank's frames), what
+        # the oracle is pinned to.  8: the frame batching of diffusers 0.32.2 ``AutoencoderKLCogVideoX._encode`` (a dependency that is
+        # not in this image: restated from its published source, parity unpinned) -- a 8n+1-frame clip is encoded as 9 frames, then 8 at a
+        # time with the causal-convolution cache carried over, so only the GroupNorm statistics see the boundaries: the first 9 frames
+        # encode exactly as a 9-frame clip (tests/test_model_gpu.py, causality property).
+        self.frame_batch = num_sample_frames_batch_size
+        self._t_in = 0
         if ch % 64 or in_channels > 8:
             raise ValueError("ch must be a multiple of 64 (one K-tile of the convolution kernel) and in_channels <= 8")
         self.config = SimpleNamespace(ch=ch, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks, in_channels=in_channels,
@@ -199,16 +206,30 @@ class CogVideoXVaeEncoder(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ forward
+    def _gn(self, x: torch.Tensor, norm: "_Norm", y: torch.Tensor):
+        """GroupNorm(32, eps 1e-6) + SiLU on a channels-last clip [B, T, H, W, C]; with frame batching the statistics are per frame batch"""
+        B, T, H, W, C = x.shape
+        fb = self.frame_batch
+        stride = max(1, (self._t_in - 1) // max(T - 1, 1)) if T > 1 else 1            # temporal compression at this level
+        if fb is None or self._t_in <= fb + 1 or (self._t_in - 1) % fb or fb % stride:
+            ops.groupnorm_silu(x.view(B, -1, C), norm.weight, norm.bias, y.view(B, -1, C), 32, 1e-6, True)
+            return
+        first, rest = fb // stride + 1, fb // stride
+        n = (T - first) // rest
+        for b in range(B):
+            ops.groupnorm_silu(x[b:b + 1, :first].reshape(1, -1, C), norm.weight, norm.bias, y[b:b + 1, :first].view(1, -1, C), 32, 1e-6, True)
+            ops.groupnorm_silu(x[b, first:].view(n, rest * H * W, C), norm.weight, norm.bias, y[b, first:].view(n, rest * H * W, C), 32, 1e-6, True)
+
     def _res(self, blk: _ResBlock, pre: str, x: torch.Tensor, pk) -> torch.Tensor:
         B, T, H, W, cin = x.shape
         cout = blk.out_channels
         E = lambda c: torch.empty(B, T, H, W, c, dtype=BF16, device=x.device)
         a = E(cin)
-        ops.groupnorm_silu(x.view(B, -1, cin), blk.norm1.weight, blk.norm1.bias, a.view(B, -1, cin), 32, 1e-6, True)
+        self._gn(x, blk.norm1, a)
         h = E(cout)
         ops.causal_conv3d(a, pk[pre + "conv1.conv"], blk.conv1.conv.bias, h)
         a2 = E(cout)
-        ops.groupnorm_silu(h.view(B, -1, cout), blk.norm2.weight, blk.norm2.bias, a2.view(B, -1, cout), 32, 1e-6, True)
+        self._gn(h, blk.norm2, a2)
         if cin != cout:
             skip = E(cout)
             ops.gemm(x.view(-1, cin), pk[pre + "nin_shortcut"], skip.view(-1, cout), blk.nin_shortcut.bias)
@@ -227,6 +248,7 @@ class CogVideoXVaeEncoder(nn.Module):
         dev = self.device
         pk = self._pack()
         B, _, T, H, W = x.shape
+        self._t_in = T
         nlev = len(c.ch_mult)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError(f"H, W must be multiples of {1 << (nlev - 1)}")
@@ -255,7 +277,7 @@ class CogVideoXVaeEncoder(nn.Module):
         h = self._res(self.mid.block_2, "mid.block_2.", h, pk)
         Bq, Tq, Hq, Wq, Cq = h.shape
         a = torch.empty_like(h)
-        ops.groupnorm_silu(h.view(Bq, -1, Cq), self.norm_out.weight, self.norm_out.bias, a.view(Bq, -1, Cq), 32, 1e-6, True)
+        self._gn(h, self.norm_out, a)
         zc = self.conv_out.conv.weight.shape[0]
         m = torch.empty(Bq, Tq, Hq, Wq, zc, dtype=BF16, device=dev)
         ops.causal_conv3d(a, pk["conv_out.conv"], self.conv_out.conv.bias, m)

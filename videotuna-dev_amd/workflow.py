@@ -42,9 +42,16 @@ class _LossFn(torch.autograd.Function):
 
 class CogVideoXWorkFlow(nn.Module):
     def __init__(self, first_stage_config=None, cond_stage_config=None, denoiser_config=None, scheduler_config=None,
-                 learning_rate: float = 6e-6, adapter_config=None, logdir=None, first_stage=None, cond_stage=None):
+                 learning_rate: float = 6e-6, adapter_config=None, logdir=None, first_stage=None, cond_stage=None,
+                 cache_encodings: bool = False):
         super().__init__()
         self.logdir = logdir
+        # opt-in per-sample cache of the frozen encoders' outputs (vt355.prefetch.EncodingCache): prompt embeddings by caption, latent
+        # moments by the batch's "index" entry; steady-state epochs then run at the pre-encoded rate
+        self.encoding_cache = None
+        if cache_encodings:
+            from .prefetch import EncodingCache
+            self.encoding_cache = EncodingCache()
         self.learning_rate = learning_rate
         # frozen encoders: explicit callables win; else the config nodes are honoured when their checkpoints exist LOCALLY
         # (cogvideo_pl.py:104-121 builds them unconditionally; offline a model name such as "DeepFloyd/t5-v1_1-xxl" cannot
@@ -125,8 +132,14 @@ class CogVideoXWorkFlow(nn.Module):
                                "they are outside this engine's hot path (SURVEY 8(f)); pass pre-encoded "
                                "{'latents','prompt_embeds'} or construct the workflow with first_stage=/cond_stage= callables")
         with torch.no_grad():
-            vids = torch.cat([self.first_stage(v) for v in batch["video"]], dim=0)
-            emb = self.cond_stage([c for c in batch["caption"]])
+            ec = self.encoding_cache
+            vae = getattr(self, "vae", None)
+            if ec is not None and "index" in batch and vae is not None:
+                vids = ec.latents(batch["index"], batch["video"], lambda v: vae.encode(v).latent_dist, vae.config.scaling_factor)
+            else:
+                vids = torch.cat([self.first_stage(v) for v in batch["video"]], dim=0)
+            caps = [c for c in batch["caption"]]
+            emb = ec.prompt_embeds(caps, self.cond_stage) if ec is not None else self.cond_stage(caps)
         return {"videos": vids, "prompt_embeds": emb}
 
     def encode_raw_batch(self, batch):

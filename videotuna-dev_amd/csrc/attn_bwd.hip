@@ -93,13 +93,19 @@
 #endif                // in flight before its MFMAs, the next segment's reads are issued between the current segment's MFMAs
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef DQ_RING
-#define DQ_RING 4
+#define DQ_RING 2
 #endif
 #ifndef VT_DQ2
 #define VT_DQ2 0
 #endif
+#ifndef VT_DMA
+#define VT_DMA (VT_PF && VT_W8 && !VT_DQ16)   // 1 = waves 4..7 stage the Q / dO tiles by LDS-DMA straight into the buffer the barrier before last freed (no
+#endif                                        // staging registers, no ds_write of the tile; waves 0..3, which carry the dQ phase, stage nothing)
 #ifndef PF_TRN
-#define PF_TRN 2      // transposed-operand pairs of a dV / dK segment in flight before its first MFMA (2: two-deep ring refilled inside the segment)
+#define PF_TRN 4      // transposed-operand pairs of a dV / dK segment in flight before its first MFMA (2: two-deep ring refilled inside the segment)
+#endif
+#ifndef PF_ROWN
+#define PF_ROWN 2     // depth of the ring of Q / dO row operands (4: all k-steps of a q-half in flight before its first MFMA)
 #endif
 #ifndef PF_R0
 #define PF_R0 0       // 1 = the first reads of a step are issued right after the previous step's barrier
@@ -321,6 +327,51 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     const float* stat_src = stat_is_lse ? lse_b : dl_b;
     const float stat_mul = stat_is_lse ? (PRESCALED ? -1.0f : -1.0f / p.scale_log2) : -1.0f;
     const int stat_lds = LSEOFF + (tid & 127) * 4;
+#if VT_DMA
+    float gstat = 0.f;
+    i32x4w rq_w, rdo_w;
+    {
+        const unsigned long long aq = (unsigned long long)qb, ad = (unsigned long long)dob;
+        rq_w = (i32x4w){(int)(unsigned)aq, (int)((aq >> 32) & 0xffffu), (int)(unsigned)((long long)(p.S - 1) * p.q_rs * 2 + 128), 0x00020000};
+        rdo_w = (i32x4w){(int)(unsigned)ad, (int)((ad >> 32) & 0xffffu), (int)(unsigned)((long long)(p.S - 1) * p.do_rs * 2 + 128), 0x00020000};
+    }
+    // wave 4 + wb owns rows [16 wb, 16 wb + 16) of both tiles: two 1-KiB pieces each (8 rows x 8 chunks; lane i fills LDS slot i of the piece,
+    // i.e. row i >> 3, position i & 7, which the images' swizzle assigns to chunk (i & 7) ^ f(row): the swizzle is applied to the SOURCE)
+    int dma_vq[2], dma_vdo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (w & 3) + 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ swz_f(row);
+        dma_vq[j] = (int)(row * p.q_rs * 2) + c * 16;
+        dma_vdo[j] = (int)(row * p.do_rs * 2) + c * 16;
+    }
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto gload = [&](int t) {                     // tile t -> buffer t & 1, free since the barrier of step t - 2
+        if (!dqw) {
+            const int q0 = t * 64;
+            const int sq = (int)((long long)q0 * p.q_rs * 2), sdo = (int)((long long)q0 * p.do_rs * 2);
+            const unsigned dst = smem_lds + QTILE + (t & 1) * 16384 + (16 * (w & 3)) * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst + j * 1024), "v"(dma_vq[j]), "s"(rq_w), "s"(sq) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst + 8192 + j * 1024), "v"(dma_vdo[j]), "s"(rdo_w), "s"(sdo) : "memory");
+            }
+            int qi = q0 + stat_i;
+            const bool ok = qi < p.S;
+            qi = ok ? qi : p.S - 1;
+            const float v = stat_src[qi] * stat_mul;
+            gstat = ok ? v : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {                  // before the barrier that publishes the tile
+        if (!dqw) {
+            *(float*)(smem + stat_lds + buf * 512) = gstat;     // threads t and t + 128 write the same value
+            __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the compiler does not know about the DMA pieces
+        }
+    };
+#else
     u32x4 gq, gdo;
     float gstat = 0.f;
     auto gload = [&](int t) {
@@ -341,6 +392,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         *(float*)(smem + stat_lds + buf * 512) = gstat;     // threads t, t+128, t+256, t+384 write the same value
     };
 
+#endif
     f32x16 dk_acc[2], dv_acc[2];          // [dt]: dK^T / dV^T of this wave's 32 keys
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -386,7 +438,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     // S'' / dP' of q-half 0 (initialised with the row constants) and the two-deep ring of Q / dO row operands are carried from step to
     // step: the first reads of step t + 1 are issued right after the barrier of step t, before anything else
     f32x16 sacc[2], pacc[2];
-    bf16x8 qa[2], doa[2];
+    bf16x8 qa[PF_ROWN], doa[PF_ROWN];
     auto rd_init = [&](const float* lsel_, int qs, int g0, int g1) {
 #pragma unroll
         for (int gg = g0; gg < g1; ++gg) {
@@ -397,13 +449,14 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         }
     };
     auto rd_rows = [&](const char* qimg_, const char* doimg_, int qs, int s_) {
-        qa[s_ & 1] = *(const bf16x8*)(qimg_ + qs * 4096 + rowrd[s_]);
-        doa[s_ & 1] = *(const bf16x8*)(doimg_ + qs * 4096 + rowrd[s_]);
+        qa[s_ % PF_ROWN] = *(const bf16x8*)(qimg_ + qs * 4096 + rowrd[s_]);
+        doa[s_ % PF_ROWN] = *(const bf16x8*)(doimg_ + qs * 4096 + rowrd[s_]);
     };
     auto rd_first = [&](int bufn) {
         const char* qn = smem + QTILE + bufn * 16384;
         rd_init((const float*)(smem + LSEOFF + bufn * 512), 0, 0, 4);
-        rd_rows(qn, qn + 8192, 0, 0); rd_rows(qn, qn + 8192, 0, 1);
+#pragma unroll
+        for (int s_ = 0; s_ < PF_ROWN; ++s_) rd_rows(qn, qn + 8192, 0, s_);
         FENCE();
     };
 #if PF_R0
@@ -449,13 +502,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             for (int qs = 0; qs < 2; ++qs) {
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
-                    sacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s_ & 1], kf[s_], sacc[qs], 0, 0, 0);
-                    pacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[s_ & 1], vf[s_], pacc[qs], 0, 0, 0);
-                    if (s_ < 2) rd_rows(qimg, doimg, qs, s_ + 2); else rd_tr(qs, s_ - 2);       // into the slot these MFMAs just read
+                    sacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s_ % PF_ROWN], kf[s_], sacc[qs], 0, 0, 0);
+                    pacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[s_ % PF_ROWN], vf[s_], pacc[qs], 0, 0, 0);
+                    if (s_ + PF_ROWN < 4) rd_rows(qimg, doimg, qs, s_ + PF_ROWN);               // into the slot these MFMAs just read
+                    if (s_ >= 2) rd_tr(qs, s_ - 2);
                     FENCE();
                 }
-#if PF_TRN == 4
-                rd_tr(qs, 2); rd_tr(qs, 3);             // land under the exp2 block
+#if PF_TRN > 2
+#pragma unroll
+                for (int jj = 2; jj < PF_TRN; ++jj) rd_tr(qs, jj);      // land under the exp2 block
                 FENCE();
 #endif
                 STAMP(2 + 3 * qs, pacc[qs][15]);
@@ -475,10 +530,10 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                     const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
                     dv_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[j % PF_TRN], __builtin_bit_cast(bf16x8, pb4), dv_acc[dt], 0, 0, 0);
                     dk_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[j % PF_TRN], __builtin_bit_cast(bf16x8, db4), dk_acc[dt], 0, 0, 0);
-                    if (PF_TRN == 2 && j < 2) rd_tr(qs, j + 2);
+                    if (j + PF_TRN < 4) rd_tr(qs, j + PF_TRN);       // into the slot these MFMAs just read
                     if (qs == 0) {                      // the other q-half's first reads ride under these MFMAs
                         rd_init(lsel, 1, j, j + 1);
-                        if (j >= 2) rd_rows(qimg, doimg, 1, j - 2);
+                        if (j >= 4 - PF_ROWN) rd_rows(qimg, doimg, 1, j - (4 - PF_ROWN));
                     }
                     FENCE();
                 }
@@ -556,6 +611,11 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         }
 #endif
         lstore(buf ^ 1);
+#if VT_DMA
+        // the predecessor's tile t (LDS-DMA the compiler does not know about) must have landed before the barrier: it was issued before
+        // this wave's previous 16 atomics (+ 1 counter store), which may stay in flight -- vector memory completes in order
+        if (has_prod && dqw) __builtin_amdgcn_s_waitcnt(has_cons ? 0x0F70 : 0x4F70);       // vmcnt(0) | vmcnt(16)
+#endif
         STAMP(8, stamp_dummy);
         __syncthreads();
         STAMP(9, stamp_dummy);

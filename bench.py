@@ -277,6 +277,9 @@ def main():
                          "(cogvideo_pl.py:792-813); default: pre-encoded latents")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
+    ap.add_argument("--allreduce-dtype", choices=["fp32", "bf16"], default="bf16",
+                    help="full fine-tuning, N > 1: wire format of the gradient all-reduce (bf16 = the reference's DDP, whose gradients are "
+                         "bf16: 3.4 GB per step; fp32 = the engine's accumulators as they are: 6.8 GB)")
     ap.add_argument("--rehearse", action="store_true",
                     help="no GPU work: the ranks only rendezvous (gloo), all-reduce one number and rank 0 prints it -- the CPU test "
                          "of the launcher / rank plumbing (tests/test_ddp_cpu.py)")
@@ -349,7 +352,7 @@ def main():
         peft = model
         st = enable_full_finetune(model)
         opt = FusedAdamW(st.params, lr=lr, fullft_state=st)
-        red = BucketedReducer(st.grad)
+        red = BucketedReducer(st.grad, wire_dtype=torch.bfloat16 if args.allreduce_dtype == "bf16" else None)
     sched = CogVideoXDPMScheduler()
 
     B, Fr, C, Hh, Ww, St = args.micro_batch, 13, 16, 60, 90, 226
@@ -543,7 +546,8 @@ def main():
                  "peak": 2500.0, "unit": "TFLOP/s", "frac": (kern["gemm"]["tflops_algorithmic"] / 2500.0) if kern.get("gemm", {}).get("tflops_algorithmic") else None}],
             "kernels": kern,
             "ddp": {"backend": (dist.get_backend() if world > 1 else None), "world_size_seen": (dist.get_world_size() if world > 1 else 1),
-                    "allreduce_bytes_per_step": int(st.grad.numel() * 4) if world > 1 else 0,
+                    "allreduce_bytes_per_step": (int(st.grad.numel() * (2 if (args.mode == "fullft" and args.allreduce_dtype == "bf16") else 4)) if world > 1 else 0),
+                    "allreduce_dtype": (args.allreduce_dtype if args.mode == "fullft" else "fp32"),
                     "dq_chains": bool(ops.attn_bwd_chain_workspace(args.micro_batch, model.config.num_attention_heads, S, dev) is not None)},
             "loss_last": loss_vals[-1], "loss_first": loss_vals[0],
         }

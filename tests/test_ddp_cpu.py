@@ -61,6 +61,29 @@ def _bucket_worker(rank, world, port, out):
     dist.barrier(); dist.destroy_process_group()
 
 
+def _bucket_bf16_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vt355.ddp import BucketedReducer, init_from_env
+    init_from_env(backend="gloo")
+    grad = torch.linspace(-1, 1, 1000) * (rank + 1)
+    red = BucketedReducer(grad, wire_dtype=torch.bfloat16)
+    for lo, hi in ((500, 1000), (0, 500)):
+        red.hook(lo, hi)
+    red.wait_all()
+    want = torch.linspace(-1, 1, 1000).to(torch.bfloat16).float() + (torch.linspace(-1, 1, 1000) * 2).to(torch.bfloat16).float()
+    out[rank] = ((grad - want).abs().max().item(), red.bytes_sent, grad.dtype == torch.float32)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_bucketed_reducer_bf16_wire_world2():
+    """the slices travel as bf16 (half the bytes), the fp32 buffer receives the bf16 sum"""
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_bucket_bf16_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        err, sent, f32 = out[r]
+        assert err <= 2 ** -7 and sent == 2000 and f32          # one bf16 rounding of a sum of magnitude <= 3
+
+
 def test_bucketed_reducer_world2():
     mgr = mp.Manager(); out = mgr.dict()
     mp.spawn(_bucket_worker, args=(2, _free_port(), out), nprocs=2, join=True)

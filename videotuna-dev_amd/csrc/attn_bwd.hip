@@ -614,7 +614,11 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #if VT_DMA
         // the predecessor's tile t (LDS-DMA the compiler does not know about) must have landed before the barrier: it was issued before
         // this wave's previous 16 atomics (+ 1 counter store), which may stay in flight -- vector memory completes in order
-        if (has_prod && dqw) __builtin_amdgcn_s_waitcnt(has_cons ? 0x0F70 : 0x4F70);       // vmcnt(0) | vmcnt(16)
+        // (step 0 has no atomics behind the DMA yet: wait for everything)
+        if (has_prod && dqw) {
+            if (has_cons || t == 0) __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x4F70);                                      // vmcnt(16)
+        }
 #endif
         STAMP(8, stamp_dummy);
         __syncthreads();

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
     // lane l lands at (row l>>4 of its 4-row block, physical chunk l&15) and fetches logical chunk (l&15) ^ swz(row): its column, hence
     // its tap and input-channel offset, are fixed for the whole kernel (per j: the row inside the K-tile changes the swizzle)
     const int drl = lane >> 4, dcp = lane & 15;
-    int a_col[4], b_ci[4], b_dt[4], b_dh[4], b_dw[4];
+    int a_col[4], b_ci[4], b_dt[4], b_dh[4], b_dw[4], b_roff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = 4 * (wave + 4 * j) + drl;
@@ -281,25 +281,39 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
         } else {
             b_ci[j] = -1; b_dw[j] = 0; b_dh[j] = 0; b_dt[j] = 0;
         }
+        b_roff[j] = (b_dt[j] * p.H + b_dh[j]) * p.W + b_dw[j];
     }
+    // The position decode of a K-tile's 64 rows (three divisions each) is done ONCE, by the first wave, two K-tiles ahead, into a
+    // small LDS table: {row index of the centre tap, t, h*stride, w*stride}; every lane then only adds its tap's
+    // constants and tests the bounds (r02: the per-lane decode of four rows cost as much issue time as the K-tile's MFMAs).
+    __shared__ int4 rowtab[2][64];
+    auto fill = [&](int kt) {
+        if (tid < 64) {
+            const int ml = kt * 64 + tid;
+            int4 e = {0, 0x40000000, 0, 0};                     // t far out of range for every tap
+            if (ml < m_cnt) {
+                const int m = m_lo + ml;
+                const int nt = cn_fastdiv(m, p.mg_hwo, p.sh_hwo), sp = m - nt * HWo;
+                const int n = cn_fastdiv(nt, p.mg_t, p.sh_t), t = nt - n * p.T;
+                const int ho = cn_fastdiv(sp, p.mg_wo, p.sh_wo), wo = sp - ho * p.Wo;
+                e.x = ((n * p.T + t) * p.H + ho * p.stride) * p.W + wo * p.stride;
+                e.y = t; e.z = ho * p.stride; e.w = wo * p.stride;
+            }
+            rowtab[kt & 1][tid] = e;
+        }
+    };
+    const unsigned ldx2 = (unsigned)(p.ldx * 2);
     auto dma = [&](int kt, int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 4 * (wave + 4 * j) + drl;
             const int ml = kt * 64 + row;
-            const int m = m_lo + ml;
+            const int4 e = rowtab[kt & 1][row];
             unsigned a_off = CN_OOB, b_off = CN_OOB;
-            if (ml < m_cnt) {
-                a_off = (unsigned)((long long)m * p.lddy * 2 + a_col[j]);
-                const int nt = cn_fastdiv(m, p.mg_hwo, p.sh_hwo), sp = m - nt * HWo;
-                const int n = cn_fastdiv(nt, p.mg_t, p.sh_t), t = nt - n * p.T;
-                const int ho = cn_fastdiv(sp, p.mg_wo, p.sh_wo), wo = sp - ho * p.Wo;
-                const int tt = t + b_dt[j], hh = ho * p.stride + b_dh[j], ww = wo * p.stride + b_dw[j];
-                if (b_ci[j] >= 0 && tt >= 0 && tt < p.T && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
-                    const long long r = (((long long)n * p.T + tt) * p.H + hh) * p.W + ww;
-                    b_off = (unsigned)(r * p.ldx * 2 + b_ci[j]);
-                }
-            }
+            if (ml < m_cnt) a_off = (unsigned)((long long)(m_lo + ml) * p.lddy * 2 + a_col[j]);
+            const int tt = e.y + b_dt[j], hh = e.z + b_dh[j], ww = e.w + b_dw[j];
+            if (b_ci[j] >= 0 && (unsigned)tt < (unsigned)p.T && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                b_off = (unsigned)(e.x + b_roff[j]) * ldx2 + (unsigned)b_ci[j];
             char* dst = smem + buf * 32768 + (wave + 4 * j) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, (int)a_off, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dst + 16384), 16, (int)b_off, 0, 0, 0);
@@ -317,11 +331,14 @@ __global__ __launch_bounds__(256, 2) void conv_dw_kernel(ConvDwParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (m_cnt + 63) / 64;
+    fill(0); fill(1);
+    __syncthreads();
     dma(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+        if (kt + 2 < nk) fill(kt + 2);                   // slot kt & 1: read by dma(kt, .) one iteration ago, behind a barrier
         const char* As = smem + buf * 32768;
         const char* Bs = As + 16384;
 #pragma unroll

@@ -101,6 +101,9 @@
 #ifndef VT_DMA
 #define VT_DMA (VT_PF && VT_W8 && !VT_DQ16)   // 1 = waves 4..7 stage the Q / dO tiles by LDS-DMA straight into the buffer the barrier before last freed (no
 #endif                                        // staging registers, no ds_write of the tile; waves 0..3, which carry the dQ phase, stage nothing)
+#ifndef VT_DMA_LATE
+#define VT_DMA_LATE 0  // 1 = waves 4..7 issue their staging pieces inside the S phase instead of right behind the barrier: measured slower (13.14 vs 12.83 ms, B=2)
+#endif
 #ifndef PF_TRN
 #define PF_TRN 4      // transposed-operand pairs of a dV / dK segment in flight before its first MFMA (2: two-deep ring refilled inside the segment)
 #endif
@@ -346,18 +349,28 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         dma_vdo[j] = (int)(row * p.do_rs * 2) + c * 16;
     }
     const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto gload = [&](int t) {                     // tile t -> buffer t & 1, free since the barrier of step t - 2
+    // tile t -> buffer t & 1, free since the barrier of step t - 2.  Two halves (Q pieces | dO pieces + row constants) so that the step can
+    // issue them at different points of its S phase: an LDS-DMA piece holds the CU's address path for ~16 cycles, and eight waves
+    // issuing theirs right behind the barrier (these + the dQ waves' chain pieces) queued for ~600 cycles
+    auto gload_q = [&](int t) {
         if (!dqw) {
-            const int q0 = t * 64;
-            const int sq = (int)((long long)q0 * p.q_rs * 2), sdo = (int)((long long)q0 * p.do_rs * 2);
+            const int sq = (int)((long long)t * 64 * p.q_rs * 2);
             const unsigned dst = smem_lds + QTILE + (t & 1) * 16384 + (16 * (w & 3)) * 128;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 2; ++j)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                              :: "s"(dst + j * 1024), "v"(dma_vq[j]), "s"(rq_w), "s"(sq) : "memory");
+        }
+    };
+    auto gload_do = [&](int t) {
+        if (!dqw) {
+            const int q0 = t * 64;
+            const int sdo = (int)((long long)q0 * p.do_rs * 2);
+            const unsigned dst = smem_lds + QTILE + (t & 1) * 16384 + (16 * (w & 3)) * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                              :: "s"(dst + 8192 + j * 1024), "v"(dma_vdo[j]), "s"(rdo_w), "s"(sdo) : "memory");
-            }
             int qi = q0 + stat_i;
             const bool ok = qi < p.S;
             qi = ok ? qi : p.S - 1;
@@ -365,6 +378,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             gstat = ok ? v : 0.f;
         }
     };
+    auto gload = [&](int t) { gload_q(t); gload_do(t); };
     auto lstore = [&](int buf) {                  // before the barrier that publishes the tile
         if (!dqw) {
             *(float*)(smem + stat_lds + buf * 512) = gstat;     // threads t and t + 128 write the same value
@@ -431,7 +445,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             }
             pf_ready = fl_load(fl_ready_prod);
         }
+#if !(VT_DMA && VT_DMA_LATE)
         gload(t1 + 1);                                 // past the end: bounds-checked loads return zeros
+#endif
     };
 #if VT_PF
     prefetch(0);
@@ -508,6 +524,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                     if (s_ >= 2) rd_tr(qs, s_ - 2);
                     FENCE();
                 }
+#if VT_DMA && VT_DMA_LATE
+                if (qs == 0) { gload_q(t + 1); FENCE(); }   // waves 4..7: the next tile's Q pieces (past the end: zeros)
+#endif
 #if PF_TRN > 2
 #pragma unroll
                 for (int jj = 2; jj < PF_TRN; ++jj) rd_tr(qs, jj);      // land under the exp2 block
@@ -545,6 +564,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 }
                 STAMP(4 + 3 * qs, dk_acc[1][15]);
                 FENCE();
+#if VT_DMA && VT_DMA_LATE
+                if (qs == 0) { gload_do(t + 1); FENCE(); }  // ... its dO pieces and row constants
+#endif
             }
         }
 #else

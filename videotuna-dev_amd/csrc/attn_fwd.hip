@@ -32,6 +32,11 @@ struct AttnFwdParams {
     const float* bias_t;   // BIAS kernels: additive score bias, TRANSPOSED [H][S keys][S queries] fp32 (same for every sample), or null
 };
 
+#ifndef VT_FWD_PF
+#define VT_FWD_PF 0      // 1 (q_prescaled kernel only) = all eight K fragments of a tile in flight before its first MFMA and the V^T fragments read
+#endif                   // under the S^T MFMAs, the issue order pinned by sched_barrier fences (what helped the backward in r02).  Measured here
+                         // (tools/kbench_fwd.py, B=2): 5.10 vs 5.01 ms -- 163 instead of 127 registers take the kernel from 4 to 3 waves per SIMD,
+                         // and with four waves per SIMD the other waves already cover the exposed LDS round trips: not enabled
 #ifndef VT_FWD_ABL
 #define VT_FWD_ABL 0     // timing-only ablations (results WRONG): 1 = K fragments read from one fixed LDS row set per step (no per-k-step reads), 2 = no V^T transposed reads, 3 = both
 #endif
@@ -174,10 +179,39 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
         const char* base = smem + buf * 16384;
 
         f32x16 st[2];
+        bf16x8 vtf[4][2];          // VT_FWD_PF: V^T fragments of the four PV pairs, read ahead
+        (void)vtf;
         if constexpr (PRESCALED) {
             // ---- lazy-max online softmax (q carries softmax_scale*log2e): the accumulators START at -m_ref, so the
             // MFMA chain delivers s - m_ref and P = exp2(st) needs no subtraction; O and l are rescaled only when some
             // row's maximum grew by more than LAZY_THR (P then stays <= 2^LAZY_THR), which is rare after the first tiles.
+#if VT_FWD_PF
+            {
+                bf16x8 kfr[4][2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int kt2 = 0; kt2 < 2; ++kt2) kfr[s][kt2] = *(const bf16x8*)(base + kt2 * 4096 + kfo[s]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int kt2 = 0; kt2 < 2; ++kt2)
+                        st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s][kt2], qf[s], s == 0 ? negm : st[kt2], 0, 0, 0);
+                    // the V^T fragments of PV pair (kt2p, s2p) = (s >> 1, s & 1), both d-tiles, ride under these MFMAs
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* vp = base + vfo[dt] + ((s >> 1) * 32 + (s & 1) * 16) * 128;
+                        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp));
+                        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp + 8 * 128));
+                        typedef __attribute__((ext_vector_type(8))) short short8v;
+                        short8v v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        vtf[s][dt] = __builtin_bit_cast(bf16x8, v8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -190,6 +224,7 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
                     st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s == 0 ? negm : st[kt2], 0, 0, 0);
                 }
             }
+#endif
             if ((t + 1) * FK > p.S) {
 #pragma unroll
                 for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -298,6 +333,12 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kt2][8 * s2 + j];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
+#if VT_FWD_PF
+                    if constexpr (PRESCALED) {
+                        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtf[2 * kt2 + s2][dt], pf, o_acc[dt], 0, 0, 0);
+                        continue;
+                    }
+#endif
 #if VT_FWD_ABL & 2
                     o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(dt + s2 + kt2) & 3], pf, o_acc[dt], 0, 0, 0);
 #else

@@ -2,7 +2,9 @@
 """bench.py -- finetune samples/sec + step time, CogVideoX-2B T2V LoRA 49x480x720 bf16 (BASELINE.json metric).
 
 One "step" = one optimizer step of the reference recipe (configs/004_cogvideox/cogvideo2b.yaml: batch_size 2,
-accumulate_grad_batches 2): 2 micro-batches x 2 samples of synthetic latents [2,13,16,60,90] + text [2,226,4096]
+accumulate_grad_batches 2 = 4 samples per optimizer step and rank).  LoRA default: the four samples run as ONE batch (--micro-batch 4
+--accum 1: the same gradient as 2 x 2, 122 of the 288 GB; pass --micro-batch 2 --accum 2 for the YAML's literal schedule, which the full
+fine-tune default keeps): synthetic latents [B,13,16,60,90] + text [B,226,4096]
 already resident in HBM -> add_noise -> DiT forward -> loss -> backward (LoRA grads) -> [DDP all-reduce] -> fused AdamW.
 Random-init weights of the 2B architecture (no checkpoints offline), nothing skipped inside the timed region.
 
@@ -123,8 +125,8 @@ def bench_vc2(args):
     ts = flow.model.train_state
     broadcast_flat(ts.flat); broadcast_flat(ts.flat_bf16)
     red = FlatGradReducer(ts.grad)
-    B = args.micro_batch if args.micro_batch != 2 else 4          # the recipe's batch_size (the CogVideoX default of this flag is 2)
-    accum = args.accum if args.accum != 2 else 1
+    B = args.micro_batch if args.micro_batch is not None else 4   # the recipe's batch_size
+    accum = args.accum if args.accum is not None else 1
     dgen = torch.Generator(device=dev).manual_seed(20230211 + rank)
 
     def make_batch():
@@ -217,7 +219,7 @@ def bench_stdit(args):
     flow.model.init_weights(7)
     flow.to(dev)
     opt = flow.configure_optimizers()
-    B = args.micro_batch if args.micro_batch != 2 else 4          # the yaml's batch_size
+    B = args.micro_batch if args.micro_batch is not None else 4   # the yaml's batch_size
     dgen = torch.Generator(device=dev).manual_seed(20230211)
     mask = torch.zeros(B, 120, dtype=torch.int64, device=dev)
     for b in range(B):
@@ -260,8 +262,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--micro-batch", type=int, default=2)
-    ap.add_argument("--accum", type=int, default=2)
+    ap.add_argument("--micro-batch", type=int, default=None, help="default: 4 (2B LoRA), 2 otherwise; vc2 / stdit: 4")
+    ap.add_argument("--accum", type=int, default=None, help="default: 1 (2B LoRA), 2 otherwise; vc2 / stdit: 1")
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["2b", "5b", "vc2", "stdit"], default="2b",
@@ -284,6 +286,12 @@ def main():
                     help="no GPU work: the ranks only rendezvous (gloo), all-reduce one number and rank 0 prints it -- the CPU test "
                          "of the launcher / rank plumbing (tests/test_ddp_cpu.py)")
     args = ap.parse_args()
+    if args.model in ("2b", "5b"):                       # vc2 / stdit resolve their own defaults
+        lora_2b = args.model == "2b" and args.mode == "lora" and not (args.text_encoder or args.vae_encoder)
+        if args.micro_batch is None:
+            args.micro_batch = 4 if lora_2b else 2
+        if args.accum is None:
+            args.accum = (4 // args.micro_batch if args.micro_batch in (1, 2, 4) and lora_2b else 2)
 
     if args.rehearse:
         from vt355.ddp import init_from_env
@@ -340,7 +348,7 @@ def main():
             p.normal_(0.0, 0.02, generator=gen)
             if name.endswith(("norm.weight", "norm_final.weight", "norm_q.weight", "norm_k.weight")):
                 p.add_(1.0)
-    lr = 6e-6 * world * args.micro_batch            # scripts/train.py:180-185  lr = world * bs * base_lr
+    lr = 6e-6 * world * 2                           # scripts/train.py:180-185  lr = world * bs * base_lr (the YAML's batch_size 2)
     if args.mode == "lora":
         model.requires_grad_(False)
         peft = get_peft_model(model, LoraConfig(r=4, lora_alpha=1.0, target_modules=["to_k", "to_q", "to_v", "to_out.0"]))
@@ -501,7 +509,7 @@ def main():
                 summ = json.load(f)
             if summ.get("provenance", {}).get("attn_bwd_src_sha16") != src:
                 traffic_note = "profiles/r02_pmc_bench_summary.json was measured on another version of attn_bwd.hip: not quoted"
-            elif args.micro_batch == 2 and args.layers == 30 and args.model == "2b":
+            elif args.micro_batch == summ.get("provenance", {}).get("micro_batch", 2) and args.layers == 30 and args.model == "2b":
                 key = [k for k in summ["traffic"] if "attn_bwd_hd64_kernel" in k][0]
                 traffic = summ["traffic"][key]["hbm_bytes_per_launch"]
                 traffic_note = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r02_pmc_bench_summary.json, same kernel "
@@ -520,8 +528,9 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("CogVideoX-2B T2V LoRA finetune 49x480x720 (configs[1]): latents [2,13,16,60,90], "
-                                    "text [2,226,4096], r=4 LoRA on to_q/k/v/out, accumulate_grad_batches 2") if args.mode == "lora" else
+            "config": {"workload": ("CogVideoX-2B T2V LoRA finetune 49x480x720 (configs[1]): latents [%d,13,16,60,90], text [%d,226,4096], r=4 LoRA on "
+                                    "to_q/k/v/out, 4 samples per optimizer step as in the YAML (batch_size 2 x accumulate_grad_batches 2), run as "
+                                    "%d micro-batch(es) of %d" % (args.micro_batch, args.micro_batch, args.accum, args.micro_batch)) if args.mode == "lora" else
                                    ("CogVideoX-2B T2V FULL finetune 49x480x720 (configs[2]): all 1.69 B weights trainable, fp32 master "
                                     "+ fused AdamW, per-block gradient slices all-reduced under the backward"),
                        "mode": args.mode, "model": "CogVideoX-" + args.model.upper() + ("" if args.model == "2b" else

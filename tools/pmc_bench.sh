@@ -34,7 +34,7 @@ def sha(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 prov = {"attn_bwd_src_sha16": sha(os.path.join(root, "videotuna-dev_amd/csrc/attn_bwd.hip")),
         "attn_fwd_src_sha16": sha(os.path.join(root, "videotuna-dev_amd/csrc/attn_fwd.hip")),
-        "lib_sha16": sha(os.path.join(root, "videotuna-dev_amd/libvt355.so")), "command": "python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline"}
+        "lib_sha16": sha(os.path.join(root, "videotuna-dev_amd/libvt355.so")), "micro_batch": 4, "command": "python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline"}
 json.dump({"provenance": prov, "traffic": res, "kernel_stats": stats}, open(out + "/summary.json", "w"), indent=1)
 for k in sorted(res, key=lambda k: -res[k]["hbm_bytes_per_launch"] * res[k]["launches"])[:8]:
     print(k[:60], res[k])

@@ -360,6 +360,23 @@ int vt_qk_rmsnorm_rope128_bwd(const void* dout, long long lddo, const void* qkv,
                               const void* gk, const float* rstd, const float* rope_cos, const float* rope_sin, float* dgq, float* dgk,
                               long long M, int H, int L, int Lout, int row_off, int S_rope, void* stream);
 
+/* ---- long-sequence attention, head_dim 128 (csrc/attn128.hip) ----------------------------------------------------------------------
+ * HunyuanVideo's joint [image; text] attention at 10^4 - 10^5 tokens: `attention(q, k, v, mode="flash", cu_seqlens_q, cu_seqlens_kv, ...)`,
+ * videotuna/models/hunyuan/hyvideo_t2v/modules/attenion.py:60-156, called from MMDoubleStreamBlock / MMSingleStreamBlock
+ * (modules/models.py:203-221, 362-378), and its autograd.  Element (b, s, head, d) of q / k / v / o / dout / dk / dv at
+ * base + b*bs + s*rs + head*128 + d (bf16; the fused qkv projection is consumed in place); kv_len: int32 [B] on the device (valid rows
+ * and keys of every sample, = cu_seqlens[2b+1] - cu_seqlens[2b]) or NULL; lse2: fp32 [B, H, S], log2-domain.
+ * Backward: delta_ws fp32 [B*H*S] scratch; dq32 fp32 accumulator with row stride dq_rs / batch stride dq_bs, ZEROED BY THE CALLER
+ * (softmax_scale-scaled sums are added atomically); dk, dv written for every row < S (zeros for keys >= kv_len[b]). */
+int vt_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* kv_len, int B, int H, int S,
+                   long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                   long long q_bs, long long k_bs, long long v_bs, long long o_bs, float softmax_scale, void* stream);
+int vt_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
+                   float* delta_ws, float* dq32, void* dk, void* dv, int B, int H, int S,
+                   long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dk_rs,
+                   long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs, long long dq_bs,
+                   long long dk_bs, long long dv_bs, float softmax_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,45 @@ def test_sp_device_core_matches_dense_attention(dev):
     for a, b_, n in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
         assert _rel(a, b_) < 2e-2, n
     assert kd.grad[1, 137:].abs().max().item() == 0 and vd.grad[1, 137:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,S,H,lens", [(2, 200, 2, (200, 137)), (1, 333, 3, None), (2, 64, 1, (1, 64)), (1, 1000, 2, (777,))])
+def test_attn128_matches_dense_attention(dev, B, S, H, lens):
+    """vt_attn128_fwd / _bwd (long-sequence head_dim-128 kernels) vs dense fp64 attention with per-sample valid lengths: output, log-sum-exp,
+    dQ, dK, dV; ragged tiles (S not a multiple of 64 / 128), a one-key sample, keys past the valid length get zero gradients"""
+    from vt355 import ops
+    gen = torch.Generator().manual_seed(S + H)
+    C = H * 128
+    qkv = torch.randn(B, S, 3 * C, generator=gen).to(BF)
+    g = torch.randn(B, S, C, generator=gen).to(BF)
+    kv = None if lens is None else torch.tensor(lens, dtype=torch.int32)
+    if kv is not None:
+        for b in range(B):
+            g[b, lens[b]:] = 0                     # padding rows carry no gradient (as in the blocks' tests)
+    qd = qkv.to(dev)
+    q, k, v = qd[:, :, :C], qd[:, :, C:2 * C], qd[:, :, 2 * C:]
+    o = torch.empty(B, S, C, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+    scale = 128 ** -0.5
+    kvd = None if kv is None else kv.to(dev)
+    ops.attn128_fwd(q, k, v, o, lse, H, scale, kv_len=kvd)
+    dq32 = torch.empty(B, S, C, device=dev); dqkv = torch.empty(B, S, 3 * C, dtype=BF, device=dev)
+    ops.attn128_bwd(q, k, v, o, g.to(dev), lse, dq32, dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], H, scale, kv_len=kvd)
+    x = qkv.double().requires_grad_(True)
+    qr, kr, vr = [t.reshape(B, S, H, 128) for t in x.split(C, dim=-1)]
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    if kv is not None:
+        dead = torch.arange(S)[None, :] >= kv[:, None].long()
+        s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vr).reshape(B, S, C)
+    ref.backward(g.double())
+    valid = torch.ones(B, S, 1, dtype=torch.float64) if kv is None else (torch.arange(S)[None, :] < kv[:, None].long()).double()[..., None]
+    assert _rel(o.double().cpu() * valid, ref * valid) < 1e-2
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634                                         # [B, H, S], log2 domain
+    vm = valid[..., 0][:, None, :]
+    assert ((lse.double().cpu() - lse_ref) * vm).abs().max().item() < 2e-2
+    gr = x.grad
+    assert _rel(dq32, gr[:, :, :C]) < 2e-2
+    assert _rel(dqkv[:, :, C:2 * C], gr[:, :, C:2 * C]) < 2e-2 and _rel(dqkv[:, :, 2 * C:], gr[:, :, 2 * C:]) < 2e-2
+    if kv is not None:
+        for b in range(B):
+            assert dqkv[b, lens[b]:, C:].abs().max().item() == 0 if lens[b] < S else True

@@ -26,3 +26,7 @@ f = t(lambda: ops.attn_gen_fwd(q, k, v, o, lse, H, hd, hd, hd ** -0.5, kv_len=kv
 g = t(lambda: ops.attn_gen_bwd(q, k, v, o, do, lse, dq, dk, dv, H, hd, hd, hd ** -0.5, kv_len=kv_len))
 fl = 4.0 * S * S * C * B
 print(f"attn_gen hd128 S={S} H={H}: fwd {f:.2f} ms = {fl / f / 1e9:.0f} TF/s; bwd {g:.2f} ms = {2 * fl / g / 1e9:.0f} TF/s algorithmic")
+dq32 = torch.empty(B, S, C, device=dev); dkb = torch.empty(B, S, C, dtype=BF, device=dev); dvb = torch.empty(B, S, C, dtype=BF, device=dev)
+f2 = t(lambda: ops.attn128_fwd(q, k, v, o, lse, H, hd ** -0.5, kv_len=kv_len))
+g2 = t(lambda: ops.attn128_bwd(q, k, v, o, do, lse, dq32, dkb, dvb, H, hd ** -0.5, kv_len=kv_len))
+print(f"attn128  hd128 S={S} H={H}: fwd {f2:.2f} ms = {fl / f2 / 1e9:.0f} TF/s; bwd {g2:.2f} ms = {2 * fl / g2 / 1e9:.0f} TF/s algorithmic (incl. delta pre-pass and dQ memset)")

@@ -1,0 +1,497 @@
+// Long-sequence flash attention for head_dim 128 (HunyuanVideo: 24 heads x 128, 10^4 - 10^5 tokens; joint [image; text] sequence with
+// per-sample valid lengths -- videotuna/models/hunyuan/hyvideo_t2v/modules/attenion.py:60-156 `attention(..., mode="flash")` with
+// cu_seqlens = [0, img + text_len, img + max_text] per sample: rows / keys past kv_len[b] are padding).  SURVEY 8(a) a16.
+// The head dimension is handled as TWO 64-wide planes: every LDS image (K, V, Q, dO tiles) is a pair of [rows][64] bf16 images with
+// 128-byte rows -- exactly the images, swizzles and MFMA operand reads of the head_dim-64 kernels (attn_fwd.hip / attn_bwd.hip), whose
+// structure this file follows; scores sum over both planes, O / dK / dV / dQ carry one accumulator set per plane.
+// vt_attn_gen (attn_gen.hip) stays the kernel for the short sequences and for head_dim 72/80; this one needs no padding of the tensors
+// and no workspace besides the fp32 dQ accumulator of the backward.
+#include "common.h"
+
+struct Attn128Params {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    const bf16_t* dout; const float* delta; float* dq32; bf16_t* dk; bf16_t* dv;
+    float* lse2;             // [B, H, S] log2-domain logsumexp of score * scale * log2(e)
+    const int* kv_len;       // [B] valid keys (and rows) per sample, or null
+    int S, H, B;
+    long long q_rs, k_rs, v_rs, o_rs, do_rs, dq_rs, dk_rs, dv_rs;
+    long long q_bs, k_bs, v_bs, o_bs, do_bs, dq_bs, dk_bs, dv_bs;
+    float scale, scale_log2;
+};
+
+#define A128_NEG (-1.0e30f)
+
+__device__ __forceinline__ bf16x8 a128_tr_pair(const char* p0, const char* p1) {
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(p0));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(p1));
+    typedef __attribute__((ext_vector_type(8))) short short8a;
+    short8a v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v8);
+}
+
+// ============================================================================================================ forward
+// One workgroup = 4 waves = 128 query rows of one (sample, head); K / V tiles of 64 keys x 2 planes staged by LDS-DMA, double buffered.
+// S^T = K Q^T (lane = query), online softmax in the log2 domain, O^T += V^T P^T with P^T taken from the S^T accumulators.
+__global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(Attn128Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];     // 2 buffers x (K plane0 | K plane1 | V plane0 | V plane1) x 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nqt = (p.S + 127) / 128;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt, bh = id / nqt;
+    const int head = bh % p.H, b = bh / p.H;
+    const int klen = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int q0 = qt * 128 + wave * 32;
+
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 128;
+    const bf16_t* kb = p.k + (size_t)b * p.k_bs + head * 128;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 128;
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 256));
+
+    bf16x8 qf[2][4];                   // B operand of S^T = K Q^T: lane holds Q[q0 + r][64 pl + 16 s + 8 h .. + 7]
+    {
+        int qrow = q0 + r;
+        if (qrow > p.S - 1) qrow = p.S - 1;
+        const bf16_t* qp = qb + (size_t)qrow * p.q_rs + 8 * h;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[pl][s] = *(const bf16x8*)(qp + 64 * pl + 16 * s);
+    }
+    // staging: a plane of a tile = 8 pieces of 1 KiB (8 keys x 128 B); wave w moves pieces w and w + 4 of every plane
+    int kd_voff[2], vd_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 8 * (wave + 4 * j) + (lane >> 3);
+        kd_voff[j] = (int)(key * p.k_rs * 2) + (((lane & 7) ^ ((key >> 1) & 7)) << 4);
+        vd_voff[j] = (int)(key * p.v_rs * 2) + (((lane & 7) ^ (((key >> 1) & 1) << 2)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+        const int ks = (int)((long long)t * 64 * p.k_rs * 2), vs = (int)((long long)t * 64 * p.v_rs * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                char* dst = smem + buf * 32768 + pl * 8192 + (wave + 4 * j) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kd_voff[j] + pl * 128, ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + 16384), 16, vd_voff[j] + pl * 128, vs, 0, 0);
+            }
+    };
+    int kfo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kfo[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) << 4);
+    int vfo[2];
+    {
+        const int g = lane >> 4, ql = (lane & 15) >> 2, pl4 = lane & 3;
+        const int keyl = 4 * (g >> 1) + ql;
+        const int x = (ql >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int chunk = 4 * dt + 2 * (g & 1) + (pl4 >> 1);
+            vfo[dt] = keyl * 128 + ((chunk ^ (x << 2)) << 4) + (pl4 & 1) * 8;
+        }
+    }
+    f32x16 o_acc[4];                    // [2 pl + dt]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_acc[c][i] = 0.f;
+    float m_run = A128_NEG, l_run = 0.f;
+    const float sc = p.scale_log2;
+    const int nt = (klen + 63) / 64;
+    if (nt > 0) dma(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma(t + 1, buf ^ 1);
+        const char* base = smem + buf * 32768;
+        f32x16 st[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2) {
+                    const bf16x8 kf = *(const bf16x8*)(base + pl * 8192 + kt2 * 4096 + kfo[s]);
+                    st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[pl][s], st[kt2], 0, 0, 0);
+                }
+        if ((t + 1) * 64 > klen) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = t * 64 + kt2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= klen) st[kt2][i] = A128_NEG;
+                }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(st[kt2][i] * sc - m_new);
+                st[kt2][i] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_acc[c][i] *= alpha;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kt2][8 * s2 + j];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* vp = base + 16384 + pl * 8192 + vfo[dt] + (kt2 * 32 + s2 * 16) * 128;
+                        o_acc[2 * pl + dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(vp, vp + 8 * 128), pf, o_acc[2 * pl + dt], 0, 0, 0);
+                    }
+            }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int qrow = q0 + r;
+    if (qrow < p.S) {
+        bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + head * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = pack2(o_acc[c][4 * g4 + 0] * inv, o_acc[c][4 * g4 + 1] * inv);
+                w[1] = pack2(o_acc[c][4 * g4 + 2] * inv, o_acc[c][4 * g4 + 3] * inv);
+                *(u32x2*)(op + c * 32 + 8 * g4 + 4 * h) = w;
+            }
+        if (h == 0) p.lse2[((size_t)b * p.H + head) * p.S + qrow] = m_run + __builtin_amdgcn_logf(l_tot);
+    }
+}
+
+static int a128_check(int B, int H, int S, long long a, long long b_, long long c, long long d) {
+    if (B <= 0 || H <= 0 || S <= 0) return VT_ERR_BAD_SHAPE;
+    if ((a % 8) || (b_ % 8) || (c % 8) || (d % 4)) return VT_ERR_BAD_SHAPE;
+    return VT_OK;
+}
+
+// q, k, v, o: element (b, s, head, d) at base + b*bs + s*rs + head*128 + d (the fused qkv projection is consumed in place).
+// kv_len: int32 [B] device pointer or NULL; rows >= kv_len[b] of sample b are computed against the valid keys (never against padding).
+extern "C" int vt_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* kv_len, int B, int H, int S,
+                              long long q_rs, long long k_rs, long long v_rs, long long o_rs,
+                              long long q_bs, long long k_bs, long long v_bs, long long o_bs, float softmax_scale, void* stream) {
+    int rc = a128_check(B, H, S, q_rs, k_rs, v_rs, o_rs);
+    if (rc != VT_OK) return rc;
+    if ((q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4) || lse2 == nullptr) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return VT_ERR_BAD_ALIGN;
+    if (((uintptr_t)o) & 7) return VT_ERR_BAD_ALIGN;
+    if ((long long)S * k_rs * 2 >= 0x7fffff00LL || (long long)S * v_rs * 2 >= 0x7fffff00LL) return VT_ERR_BAD_SHAPE;
+    Attn128Params p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse2 = lse2; p.kv_len = kv_len;
+    p.S = S; p.H = H; p.B = B;
+    p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
+    p.scale = softmax_scale; p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const int nqt = (S + 127) / 128;
+    hipLaunchKernelGGL(attn128_fwd_kernel, dim3((unsigned)(nqt * H * B)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+
+// ============================================================================================================ backward
+// Key-stationary, as attn_bwd.hip: one workgroup = 4 waves (one per SIMD, the whole 512-register file each) = 128 keys of one (sample, head);
+// wave w keeps K / V fragments and dK^T / dV^T accumulators (2 planes x 2 d-tiles each) of its 32 keys while the workgroup sweeps the
+// queries 64 rows per step.  S = Q K^T and dP = dO V^T with the key on the MFMA lane (accumulators start from -lse2/c and -delta, so
+// P = exp2(c S'') and dS = P dP' need no subtraction); P / dS feed dV^T += dO^T P and dK^T += Q^T dS from registers; dS crosses LDS once
+// ([128 keys][64 q] image, double buffered) and every wave computes one 32x32 tile of dQ per plane over all 128 keys, added to the fp32 dQ
+// buffer with buffer_atomic_add_f32.  Q / dO tiles (2 planes each) are staged by LDS-DMA, double buffered; one barrier per step.
+#define B128_KIMG 0            // 2 planes x 128 keys x 128 B
+#define B128_DSIMG 32768       // 2 buffers x 128 keys x 128 B
+#define B128_QTILE 65536       // 2 buffers x (Q plane 0 | Q plane 1 | dO plane 0 | dO plane 1) x 8 KiB
+#define B128_STAT 131072       // 2 buffers x (64 x -lse2/c | 64 x -delta) fp32
+#define B128_LDS 132096
+
+__device__ __forceinline__ int b128_swz_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int b128_swz_off(int row, int chunk) { return row * 128 + ((chunk ^ b128_swz_f(row)) << 4); }
+
+__global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[B128_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..3
+    const int r = lane & 31, h = lane >> 5, g = lane >> 4, ql = (lane & 15) >> 2, pl4 = lane & 3;
+    const int nkb = (p.S + 127) / 128;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = id % nkb, bh = id / nkb;
+    const int head = bh % p.H, b = bh / p.H;
+    const int key0 = kblk * 128;
+    const int klen = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 128;
+    const bf16_t* kb_ = p.k + (size_t)b * p.k_bs + head * 128;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 128;
+    const bf16_t* dob = p.dout + (size_t)b * p.do_bs + head * 128;
+    __amdgpu_buffer_rsrc_t rq = make_rsrc(qb, (unsigned)((long long)(p.S - 1) * p.q_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb_, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rdo = make_rsrc(dob, (unsigned)((long long)(p.S - 1) * p.do_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rdq = make_rsrc(p.dq32 + (size_t)b * p.dq_bs + head * 128, (unsigned)((long long)(p.S - 1) * p.dq_rs * 4 + 512));
+    const float* lse_b = p.lse2 + (size_t)bh * p.S;
+    const float* dl_b = p.delta + (size_t)bh * p.S;
+
+    // ---- K block image (B operand of dQ), both planes: 128 keys x 16 chunks, 8 per thread ----
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j;
+        const int key = i >> 4, c16 = i & 15;
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)((key0 + key) * p.k_rs * 2) + c16 * 16, 0, 0));
+        *(u32x4*)(smem + B128_KIMG + (c16 >> 3) * 16384 + b128_swz_off(key, c16 & 7)) = v;
+    }
+    bf16x8 kf[2][4], vf[2][4];
+    {
+        const int key = key0 + 32 * w + r;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kf[pl][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(key * p.k_rs * 2) + (64 * pl + 16 * s + 8 * h) * 2, 0, 0));
+                vf[pl][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(key * p.v_rs * 2) + (64 * pl + 16 * s + 8 * h) * 2, 0, 0));
+            }
+    }
+    const float kmask = (key0 + 32 * w + r) >= klen ? A128_NEG : 0.f;
+
+    int rowrd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rowrd[s] = r * 128 + (((2 * s + h) ^ b128_swz_f(r)) << 4);
+    int trA[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec) {
+            const int fx = ((ql >> 1) << 2) | (sec << 1) | h;
+            trA[dt][sec] = (4 * h + ql + 8 * sec) * 128 + (((4 * dt + 2 * (g & 1) + (pl4 >> 1)) ^ fx) << 4) + (pl4 & 1) * 8;
+        }
+    const int qs_w = w & 1, dt_w = w >> 1;                // dQ phase: (q-half, d-half) of each plane's 64x64 tile
+    int trQA[2], trQB[2];
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+        const int fx = ((ql >> 1) << 2) | (h << 1) | sec;
+        const int row = (8 * h + ql + 4 * sec) * 128;
+        trQA[sec] = row + (((4 * qs_w + 2 * (g & 1) + (pl4 >> 1)) ^ fx) << 4) + (pl4 & 1) * 8;
+        trQB[sec] = row + (((4 * dt_w + 2 * (g & 1) + (pl4 >> 1)) ^ fx) << 4) + (pl4 & 1) * 8;
+    }
+    const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
+    const int dq_rowb = (int)(p.dq_rs * 4);
+    const int fr = b128_swz_f(r);
+
+    // ---- staging: wave w moves rows [16 w, 16 w + 16) of the four plane images of a tile: two 1-KiB pieces each ----
+    int dma_vq[2], dma_vdo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * w + 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ b128_swz_f(row);
+        dma_vq[j] = (int)(row * p.q_rs * 2) + c * 16;
+        dma_vdo[j] = (int)(row * p.do_rs * 2) + c * 16;
+    }
+    const float c_inv = -1.0f / p.scale_log2;
+    auto stage = [&](int t) {                             // tile t -> buffer t & 1
+        const int q0 = t * 64;
+        const int sq = (int)((long long)q0 * p.q_rs * 2), sdo = (int)((long long)q0 * p.do_rs * 2);
+        char* dst = smem + B128_QTILE + (t & 1) * 32768 + (16 * w) * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(dst + pl * 8192 + j * 1024), 16, dma_vq[j] + pl * 128, sq, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dst + 16384 + pl * 8192 + j * 1024), 16, dma_vdo[j] + pl * 128, sdo, 0, 0);
+            }
+        if (tid < 128) {
+            int qi = q0 + (tid & 63);
+            const bool ok = qi < p.S;
+            qi = ok ? qi : p.S - 1;
+            const float v = (tid < 64) ? lse_b[qi] * c_inv : -dl_b[qi];
+            *(float*)(smem + B128_STAT + (t & 1) * 512 + tid * 4) = ok ? v : 0.f;
+        }
+    };
+
+    f32x16 dk_acc[2][2], dv_acc[2][2];                    // [plane][d-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dk_acc[a][c][i] = 0.f; dv_acc[a][c][i] = 0.f; }
+
+    const float sc = p.scale_log2;
+    const int nsteps = (p.S + 63) / 64;
+    stage(0);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nsteps) stage(t + 1);
+        const char* tile = smem + B128_QTILE + buf * 32768;          // Q planes at +0, +8192; dO planes at +16384, +24576
+        const float* lsel = (const float*)(smem + B128_STAT + buf * 512);
+        char* dsimg = smem + B128_DSIMG + buf * 16384;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const f32x4 a = *(const f32x4*)(lsel + 32 * qs + 8 * gg + 4 * h);
+                const f32x4 c = *(const f32x4*)(lsel + 64 + 32 * qs + 8 * gg + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sacc[4 * gg + e] = a[e] + kmask; pacc[4 * gg + e] = c[e]; }
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 qa = *(const bf16x8*)(tile + pl * 8192 + qs * 4096 + rowrd[s]);
+                    const bf16x8 doa = *(const bf16x8*)(tile + 16384 + pl * 8192 + qs * 4096 + rowrd[s]);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[pl][s], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, vf[pl][s], pacc, 0, 0, 0);
+                }
+            unsigned pw[8], dw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p0 = __builtin_amdgcn_exp2f(sacc[2 * i] * sc);
+                const float p1 = __builtin_amdgcn_exp2f(sacc[2 * i + 1] * sc);
+                pw[i] = pack2(p0, p1);
+                dw[i] = pack2(p0 * pacc[2 * i], p1 * pacc[2 * i + 1]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 pb4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+                const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, pb4), dsb = __builtin_bit_cast(bf16x8, db4);
+                const int ro = (32 * qs + 16 * s2) * 128;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* qimg = tile + pl * 8192 + ro, *doimg = tile + 16384 + pl * 8192 + ro;
+                        dv_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(doimg + trA[dt][0], doimg + trA[dt][1]), pb, dv_acc[pl][dt], 0, 0, 0);
+                        dk_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(qimg + trA[dt][0], qimg + trA[dt][1]), dsb, dk_acc[pl][dt], 0, 0, 0);
+                    }
+            }
+            char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
+                *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+            }
+        }
+        __syncthreads();
+        // ---- dQ: one 32 x 32 tile per plane and wave over all 128 keys ----
+        const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            f32x16 dq_acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
+#pragma unroll
+            for (int s3 = 0; s3 < 8; ++s3) {
+                const bf16x8 fa = a128_tr_pair(dsimg + s3 * 2048 + trQA[0], dsimg + s3 * 2048 + trQA[1]);
+                const bf16x8 fb = a128_tr_pair(smem + B128_KIMG + pl * 16384 + s3 * 2048 + trQB[0], smem + B128_KIMG + pl * 16384 + s3 * 2048 + trQB[1]);
+                dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, dq_acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff + pl * 256, soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
+        }
+    }
+    // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----
+    {
+        const int key = key0 + 32 * w + r;
+        if (key < p.S) {
+            bf16_t* dkp = p.dk + (size_t)b * p.dk_bs + (size_t)key * p.dk_rs + head * 128;
+            bf16_t* dvp = p.dv + (size_t)b * p.dv_bs + (size_t)key * p.dv_rs + head * 128;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        u32x2 a, c;
+                        a[0] = pack2(dk_acc[pl][dt][4 * gg + 0] * p.scale, dk_acc[pl][dt][4 * gg + 1] * p.scale);
+                        a[1] = pack2(dk_acc[pl][dt][4 * gg + 2] * p.scale, dk_acc[pl][dt][4 * gg + 3] * p.scale);
+                        c[0] = pack2(dv_acc[pl][dt][4 * gg + 0], dv_acc[pl][dt][4 * gg + 1]);
+                        c[1] = pack2(dv_acc[pl][dt][4 * gg + 2], dv_acc[pl][dt][4 * gg + 3]);
+                        *(u32x2*)(dkp + 64 * pl + 32 * dt + 8 * gg + 4 * h) = a;
+                        *(u32x2*)(dvp + 64 * pl + 32 * dt + 8 * gg + 4 * h) = c;
+                    }
+        }
+    }
+}
+
+// delta[b,h,s] = sum_d dO * O over the 128 elements of a head row: 16 lanes per row
+__global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* o, const bf16_t* dout, float* delta, int B, int H, int S,
+                                                            long long o_rs, long long do_rs, long long o_bs, long long do_bs) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid >> 4;
+    const int sub = (int)(gid & 15);
+    const long long total = (long long)B * S * H;
+    float acc = 0.f;
+    int hh = 0; long long bs = 0;
+    if (row < total) {
+        hh = (int)(row % H); bs = row / H;
+        const int s = (int)(bs % S), b = (int)(bs / S);
+        const u32x4 a = *(const u32x4*)(o + (size_t)b * o_bs + (size_t)s * o_rs + hh * 128 + sub * 8);
+        const u32x4 c = *(const u32x4*)(dout + (size_t)b * do_bs + (size_t)s * do_rs + hh * 128 + sub * 8);
+        float fa[8], fc[8];
+        unpack8(a, fa); unpack8(c, fc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += fa[i] * fc[i];
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+    if (row < total && sub == 0) delta[((size_t)(bs / S) * H + hh) * S + (bs % S)] = acc;
+}
+
+// dq32: fp32 accumulator (element (b, s, head, d) at b*dq_bs + s*dq_rs + head*128 + d), ZEROED BY THE CALLER, scaled sums are added to it;
+// dk, dv bf16 like k, v (every row < S is written; keys >= kv_len[b] get zeros).  delta_ws: fp32 [B*H*S] scratch.
+extern "C" int vt_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
+                              float* delta_ws, float* dq32, void* dk, void* dv, int B, int H, int S,
+                              long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dk_rs,
+                              long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs, long long dq_bs,
+                              long long dk_bs, long long dv_bs, float softmax_scale, void* stream) {
+    int rc = a128_check(B, H, S, q_rs, k_rs, v_rs, dk_rs);
+    if (rc != VT_OK) return rc;
+    if ((o_rs % 8) || (do_rs % 8) || (dv_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8) || (do_bs % 8) || (dk_bs % 4) || (dv_bs % 4))
+        return VT_ERR_BAD_SHAPE;
+    if (lse2 == nullptr || delta_ws == nullptr || dq32 == nullptr || dq_rs < (long long)H * 128) return VT_ERR_BAD_SHAPE;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o) | ((uintptr_t)dout)) & 15) return VT_ERR_BAD_ALIGN;
+    if ((((uintptr_t)dk) | ((uintptr_t)dv)) & 7) return VT_ERR_BAD_ALIGN;
+    const long long lim = 0x7fffff00LL;
+    if ((long long)S * q_rs * 2 >= lim || (long long)S * k_rs * 2 >= lim || (long long)S * v_rs * 2 >= lim || (long long)S * do_rs * 2 >= lim ||
+        (long long)S * dq_rs * 4 >= lim) return VT_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const long long total = (long long)B * S * H * 16;
+        hipLaunchKernelGGL(attn128_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws,
+                           B, H, S, o_rs, do_rs, o_bs, do_bs);
+    }
+    Attn128Params p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout; p.lse2 = const_cast<float*>(lse2);
+    p.delta = delta_ws; p.dq32 = dq32; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.kv_len = kv_len;
+    p.S = S; p.H = H; p.B = B;
+    p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.do_rs = do_rs; p.dq_rs = dq_rs; p.dk_rs = dk_rs; p.dv_rs = dv_rs;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.do_bs = do_bs; p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs;
+    p.scale = softmax_scale; p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    const int nkb = (S + 127) / 128;
+    hipLaunchKernelGGL(attn128_bwd_kernel, dim3((unsigned)(nkb * H * B)), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}

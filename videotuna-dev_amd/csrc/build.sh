@@ -13,7 +13,7 @@ mkdir -p "$OBJ"
 # backward (15.70 -> 15.33 ms) but not the shipped eight-wave one (14.3 -> 15.2) nor the GEMMs (-2..4 %): default everywhere.
 sched_of() { local v="VT_SCHED_$1"; if [ -n "${!v:-}" ]; then echo "${!v}"; fi; }
 pids=()
-for f in api gemm_bf16 gemm_big_bf16 gemm_pc_bf16 gemm_nt_bf16 attn_fwd attn_bwd norm elementwise lora reduce t5 groupnorm conv3d convnd unet_ops attn_small attn_gen gemm_fp8 qknorm128; do
+for f in api gemm_bf16 gemm_big_bf16 gemm_pc_bf16 gemm_nt_bf16 attn_fwd attn_bwd norm elementwise lora reduce t5 groupnorm conv3d convnd unet_ops attn_small attn_gen gemm_fp8 qknorm128 attn128; do
   if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/gemm_epilogue.h" -nt "$OBJ/$f.o" ] || [ "$HERE/build.sh" -nt "$OBJ/$f.o" ]; then
     st="$(sched_of $f)"; extra=""; [ -n "$st" ] && [ "$st" != default ] && extra="-mllvm -amdgpu-sched-strategy=$st"
     $HIPCC $FLAGS $extra -c "$HERE/$f.hip" -o "$OBJ/$f.o" &

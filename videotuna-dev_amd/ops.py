@@ -835,3 +835,34 @@ def qk_rmsnorm_rope128_bwd(dout, qkv, dqkv, gq, gk, rstd, dgq, dgk, H: int, L: i
                                                    gq.data_ptr(), gk.data_ptr(), rstd.data_ptr(), _p(cos), _p(sin), dgq.data_ptr(), dgk.data_ptr(),
                                                    qkv.shape[0], H, L, Lout, row_off, 0 if cos is None else cos.shape[0], _stream()),
           "vt_qk_rmsnorm_rope128_bwd")
+
+
+def attn128_fwd(q, k, v, o, lse2, H: int, scale: float, kv_len=None):
+    """head_dim 128, long sequences (csrc/attn128.hip).  q, k, v, o: [B, S, >= H*128] bf16 views; lse2 fp32 [B, H, S]; kv_len int32 [B] | None"""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        _req(t, BF16, n, 3)
+    _req(lse2, torch.float32, "lse2", 3)
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len", 1)
+    B, S = q.shape[0], q.shape[1]
+    if k.shape[1] != S or v.shape[1] != S:
+        raise ValueError("attn128: self-attention over one joint sequence (queries and keys share S)")
+    check(load_library().vt_attn128_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), _p(kv_len), B, H, S,
+                                        q.stride(1), k.stride(1), v.stride(1), o.stride(1), q.stride(0), k.stride(0), v.stride(0), o.stride(0),
+                                        scale, _stream()), "vt_attn128_fwd")
+
+
+def attn128_bwd(q, k, v, o, do, lse2, dq32, dk, dv, H: int, scale: float, kv_len=None):
+    """dq32: fp32 [B, S, H*128] accumulator, zeroed here; dk, dv bf16 views like k, v"""
+    for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dk", dk), ("dv", dv)):
+        _req(t, BF16, n, 3)
+    _req(dq32, torch.float32, "dq32", 3)
+    B, S = q.shape[0], q.shape[1]
+    delta = torch.empty(B * H * S, dtype=torch.float32, device=q.device)
+    dq32.zero_()
+    with _timed("attn128_bwd", 8.0 * S * S * H * 128 * B):
+        check(load_library().vt_attn128_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse2.data_ptr(), _p(kv_len),
+                                            delta.data_ptr(), dq32.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S,
+                                            q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1), dq32.stride(1), dk.stride(1), dv.stride(1),
+                                            q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq32.stride(0), dk.stride(0), dv.stride(0),
+                                            scale, _stream()), "vt_attn128_bwd")

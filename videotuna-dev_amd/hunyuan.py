@@ -5,15 +5,14 @@ vt355.unet), plus the flow-matching loss of ``HunyuanVideoWorkFlow.training_step
 
 What runs where: SiLU -> Linear modulation (small GEMM, fp32 out); LayerNorm(no affine) + modulate in vt_ln_modulate; fused qkv GEMM;
 per-head RMS q/k norm + rotary embedding of the image tokens + the [image; text] concatenation in ONE pass (vt_qk_rmsnorm_rope128);
-joint attention with per-sample valid lengths through vt_attn_gen (head_dim 128); projections / MLPs with GELU-tanh and gated
+joint attention with per-sample valid lengths through vt_attn128_fwd / _bwd (the long-sequence head_dim-128 kernels); projections / MLPs with GELU-tanh and gated
 residuals in the GEMM epilogues; the single block's ``linear1`` split into its qkv and MLP row ranges (the GELU lives in the second
 GEMM's epilogue, both write into one [attn | gelu(mlp)] buffer that ``linear2`` reads).  ``fp8=True`` runs the block Linears' FORWARD
 on the fp8 matrix cores (vt_gemm_fp8: E4M3 weights with per-tensor scale as the reference's fp8_optimization.py stores them, activations
 quantised per tensor on the fly); gradients stay bf16.
 
 NOT built (recorded in DESIGN.md): the embedders / token refiner / final layer of HYVideoDiffusionTransformer, the diffusers
-``HunyuanVideoTransformer3DModel`` key map and LoRA wrappers of the shipped recipe, and a long-sequence head_dim-128 attention kernel
-(vt_attn_gen is a simple kernel: fine for tests and the 10^4-token recipe, not tuned).  Padding text rows attend to the valid keys here
+``HunyuanVideoTransformer3DModel`` key map and LoRA wrappers of the shipped recipe, (the head_dim-128 attention backward is atomics-only: no dQ hand-off chains yet).  Padding text rows attend to the valid keys here
 (the reference gives them their own segment, attenion.py:34-57); they are never read by valid rows or by the loss.
 """
 from __future__ import annotations
@@ -215,7 +214,7 @@ class _HYRun(_STRun):
         o3 = o_out.view(B, Lj, o_out.shape[1]) if o_out.is_contiguous() else o_out.as_strided((B, Lj, C), (Lj * o_out.stride(0), o_out.stride(0), 1))
         lse = self.E(B, H, Lj, dt=F32)
         scale = 128 ** -0.5
-        ops.attn_gen_fwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], lse, H, 128, 128, scale, kv_len=kv_len)
+        ops.attn128_fwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], lse, H, scale, kv_len=kv_len)
         ov = _Var(o_out)
         if self.save:
             def bwd_joint_attention():
@@ -223,10 +222,10 @@ class _HYRun(_STRun):
                 g3 = g.view(B, Lj, g.shape[1]) if g.is_contiguous() else g.as_strided((B, Lj, C), (Lj * g.stride(0), g.stride(0), 1))
                 dj = self.E(B * Lj, 3 * C)
                 d3 = dj.view(B, Lj, 3 * C)
-                dk = self.E(B, Lj, C, dt=F32); dv = self.E(B, Lj, C, dt=F32)
-                ops.attn_gen_bwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], g3[:, :, :C], lse, d3[:, :, :C], dk, dv, H, 128, 128,
-                                 scale, kv_len=kv_len)
-                ops.residual_cast(dk.view(B * Lj, C), None, dj[:, C:2 * C]); ops.residual_cast(dv.view(B * Lj, C), None, dj[:, 2 * C:])
+                dq32 = self.E(B, Lj, C, dt=F32)
+                ops.attn128_bwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], g3[:, :, :C], lse, dq32, d3[:, :, C:2 * C],
+                                d3[:, :, 2 * C:], H, scale, kv_len=kv_len)
+                ops.residual_cast(dq32.view(B * Lj, C), None, dj[:, :C])
                 djoint_ref[0] = dj
             self.tape.append(bwd_joint_attention)
         return ov

@@ -17,7 +17,7 @@ gradient of a text tensor, never a partial sum.  Image rows are sharded.  Under 
 Parameters that only see text rows then have identical gradients on every rank; parameters that see image rows need a sum over the group
 (the caller's job, with text-row contributions pre-scaled by 1/P where one matrix serves both).
 
-``core(q, k, v, kv_len) -> out`` is the local attention over [B, S, h, d] operands (on the device: vt355.ops.attn_gen_fwd / _bwd wrapped
+``core(q, k, v, kv_len) -> out`` is the local attention over [B, S, h, d] operands (on the device: vt355.ops.attn128_fwd / _bwd wrapped
 in an autograd.Function; in the CPU tests: a dense torch statement).  Nothing here touches ``oracle/``.
 """
 from __future__ import annotations
@@ -133,7 +133,7 @@ def ulysses_joint_attention(core: Callable, q_img, k_img, v_img, q_txt, k_txt, v
 
 
 class _DeviceCore(torch.autograd.Function):
-    """vt_attn_gen (head_dim 128) as the local attention: q, k, v [B, S, h, 128] bf16, kv_len int32 [B] | None"""
+    """vt_attn128 (long-sequence head_dim 128) as the local attention: q, k, v [B, S, h, 128] bf16, kv_len int32 [B] | None"""
 
     @staticmethod
     def forward(ctx, q, k, v, kv_len):
@@ -144,7 +144,7 @@ class _DeviceCore(torch.autograd.Function):
         q3, k3, v3 = (t.contiguous().view(B, S, h * d) for t in (q, k, v))
         o = torch.empty_like(q3)
         lse = torch.empty(B, h, S, dtype=torch.float32, device=q.device)
-        ops.attn_gen_fwd(q3, k3, v3, o, lse, h, 128, 128, d ** -0.5, kv_len=kv_len)
+        ops.attn128_fwd(q3, k3, v3, o, lse, h, d ** -0.5, kv_len=kv_len)
         ctx.save_for_backward(q3, k3, v3, o, lse)
         ctx.kv_len, ctx.h = kv_len, h
         return o.view(B, S, h, d)
@@ -154,11 +154,11 @@ class _DeviceCore(torch.autograd.Function):
         from . import ops
         q3, k3, v3, o, lse = ctx.saved_tensors
         B, S, C = q3.shape
-        dq = torch.empty_like(q3)
-        dk = torch.empty(B, S, C, dtype=torch.float32, device=q3.device); dv = torch.empty_like(dk)
-        ops.attn_gen_bwd(q3, k3, v3, o, g.contiguous().view(B, S, C), lse, dq, dk, dv, ctx.h, 128, 128, 128 ** -0.5, kv_len=ctx.kv_len)
+        dq32 = torch.empty(B, S, C, dtype=torch.float32, device=q3.device)
+        dk = torch.empty_like(q3); dv = torch.empty_like(q3)
+        ops.attn128_bwd(q3, k3, v3, o, g.contiguous().view(B, S, C), lse, dq32, dk, dv, ctx.h, 128 ** -0.5, kv_len=ctx.kv_len)
         sh = (B, S, ctx.h, 128)
-        return dq.view(sh), dk.to(q3.dtype).view(sh), dv.to(q3.dtype).view(sh), None
+        return dq32.to(q3.dtype).view(sh), dk.view(sh), dv.view(sh), None
 
 
 def device_core(q, k, v, kv_len):

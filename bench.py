@@ -257,6 +257,74 @@ def bench_stdit(args):
                       "step_tflops_algorithmic": 3.0 * fwd_tflop * B * args.steps / elapsed, "loss_first": lv[0], "loss_last": lv[-1]}), flush=True)
 
 
+def bench_hunyuan(args):
+    """extra data point: the HunyuanVideo block trunk (vt355.hunyuan.HunyuanBlocks) at the shipped recipe's sequence -- 544x960x17f =
+    10 200 image tokens + 256 text tokens (ragged), d = 3072, 24 x 128 -- at a REDUCED DEPTH (4 double + 8 single of the model's 20 + 40:
+    the full 12.8 B-parameter trunk does not fit one GPU with fp32 master weights and Adam moments), full fine-tune of those blocks,
+    flow-matching loss on the image rows."""
+    import torch
+    from vt355 import ops
+    from vt355.ddp import init_from_env
+    from vt355.hunyuan import HunyuanBlocks, flow_matching_loss
+    from vt355.optim import FusedAdamW
+    rank, local, world = init_from_env(os.environ.get("VT_DDP_BACKEND"))
+    assert world == args.gpus == 1, "the HunyuanVideo line is single-GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nd, ns = (4, 8) if args.layers == 30 else (max(1, args.layers // 3), max(1, args.layers - args.layers // 3))
+    D, H, Li, Lt = 3072, 24, 10200, 256
+    B = args.micro_batch if args.micro_batch is not None else 1
+    model = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=nd, mm_single_blocks_depth=ns).to(dev).init_weights(11)
+    ts = model.enable_training()
+    opt = FusedAdamW(ts.params, lr=1e-5, fullft_state=ts)
+    g = torch.Generator(device=dev).manual_seed(20230211)
+    ang = torch.rand(Li, 64, device=dev, generator=g) * 6.28
+    freqs = (torch.repeat_interleave(ang.cos(), 2, dim=1).contiguous(), torch.repeat_interleave(ang.sin(), 2, dim=1).contiguous())
+    tv = torch.tensor([Lt - 37 * (b % 5) for b in range(B)], device=dev)
+    losses = []
+    ops.profile_reset(True)
+
+    def step():
+        img = torch.randn(B, Li, D, device=dev, generator=g).to(torch.bfloat16)
+        txt = torch.randn(B, Lt, D, device=dev, generator=g).to(torch.bfloat16)
+        vec = torch.randn(B, D, device=dev, generator=g).to(torch.bfloat16)
+        x0 = torch.randn(B, Li, D, device=dev, generator=g); noise = torch.randn(B, Li, D, device=dev, generator=g)
+        out = model(img, txt, vec, tv, freqs)
+        loss, dpred = flow_matching_loss(out[:, :Li].contiguous(), x0, noise)
+        dfull = torch.zeros_like(out); dfull[:, :Li] = dpred
+        out.backward(dfull)
+        losses.append(loss.detach())
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, work = ops.profile_collect(), ops.profile_work()
+    kern = {k: {"avg_ms": ms, "launches": n, **({"tflops_algorithmic": work[k] / (ms * n) / 1e9} if work.get(k) else {})} for k, (ms, n) in prof.items()}
+    S = Li + Lt
+    # per block forward: linears + attention 4 S^2 d; double: img+txt streams (qkv, proj, fc1, fc2 = 24 S d^2 over both streams); single: linear1 + linear2
+    fwd_double = 24.0 * S * D * D + 4.0 * S * S * D
+    fwd_single = 2.0 * S * D * (3 * D + 4 * D) + 2.0 * S * (D + 4 * D) * D + 4.0 * S * S * D
+    step_tf = 3.0 * B * (nd * fwd_double + ns * fwd_single) / 1e12
+    lv = [float(x) for x in torch.stack(losses[-args.steps:]).cpu()]
+    print(json.dumps({"metric": "finetune samples/sec, HunyuanVideo block trunk (4 double + 8 single of 20 + 40) 544x960x17f full-FT bf16",
+                      "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                      "data": "synthetic",
+                      "config": {"workload": "HunyuanVideo MMDoubleStreamBlock / MMSingleStreamBlock trunk (configs[4] family, NOT the headline config and "
+                                             f"NOT the whole model): {nd} double + {ns} single blocks, image tokens {Li} + text {Lt} (valid {tv.tolist()}), "
+                                             "d 3072, 24 x 128, all block weights trained, flow-matching loss",
+                                 "micro_batch": B, "double_blocks": nd, "single_blocks": ns, "weights": "seeded random init"},
+                      "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1), "step_tflops_algorithmic": step_tf * args.steps / elapsed,
+                      "kernels": kern, "loss_first": lv[0], "loss_last": lv[-1]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +334,7 @@ def main():
     ap.add_argument("--accum", type=int, default=None, help="default: 1 (2B LoRA), 2 otherwise; vc2 / stdit: 1")
     ap.add_argument("--layers", type=int, default=30, help="debug only; anything but 30 is not the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["2b", "5b", "vc2", "stdit"], default="2b",
+    ap.add_argument("--model", choices=["2b", "5b", "vc2", "stdit", "hunyuan"], default="2b",
                     help="2b = the benchmark (BASELINE configs[1]); 5b = CogVideoX-5B dimensions (48 heads, 42 layers, rotary q/k) -- "
                          "extra data point, labelled as such, never the headline line; vc2 = BASELINE configs[3], the VideoCrafter2 "
                          "320x512 UNet (full fine-tune of 1.41 B weights, latents [4,4,16,40,64]) -- its own metric line")
@@ -313,6 +381,8 @@ def main():
         return bench_vc2(args)
     if args.model == "stdit":
         return bench_stdit(args)
+    if args.model == "hunyuan":
+        return bench_hunyuan(args)
 
     from vt355 import ops
     from vt355.ddp import BucketedReducer, FlatGradReducer, broadcast_flat, init_from_env

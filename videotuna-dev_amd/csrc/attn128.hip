@@ -308,24 +308,43 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
         dma_vdo[j] = (int)(row * p.do_rs * 2) + c * 16;
     }
     const float c_inv = -1.0f / p.scale_log2;
-    auto stage = [&](int t) {                             // tile t -> buffer t & 1
+    // The tile pieces go through inline asm: LDS-DMA the compiler knows about is waited for with vmcnt(0) at every barrier, and vector
+    // memory completes in order -- the step would wait for its own 32 dQ atomics.  Issued right behind the barrier, BEFORE the dQ phase's
+    // atomics, the pieces of tile t + 2 are complete once all but the 32 youngest operations are (s_waitcnt vmcnt(32) before the barrier).
+    typedef int i32x4a __attribute__((ext_vector_type(4)));
+    i32x4a rq_w, rdo_w;
+    {
+        const unsigned long long aq = (unsigned long long)qb, ad = (unsigned long long)dob;
+        rq_w = (i32x4a){(int)(unsigned)aq, (int)((aq >> 32) & 0xffffu), (int)(unsigned)((long long)(p.S - 1) * p.q_rs * 2 + 256), 0x00020000};
+        rdo_w = (i32x4a){(int)(unsigned)ad, (int)((ad >> 32) & 0xffffu), (int)(unsigned)((long long)(p.S - 1) * p.do_rs * 2 + 256), 0x00020000};
+    }
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    float gstat = 0.f;
+    bool gstat_ok = false;
+    const float* stat_src = (tid & 64) ? dl_b : lse_b;    // threads 0..63: -lse2 / c, 64..127: -delta (128..255 load a copy nobody stores)
+    const float stat_mul = (tid & 64) ? -1.0f : c_inv;
+    auto stage = [&](int t) {                             // tile t -> buffer t & 1 (free since the barrier of step t - 2)
         const int q0 = t * 64;
         const int sq = (int)((long long)q0 * p.q_rs * 2), sdo = (int)((long long)q0 * p.do_rs * 2);
-        char* dst = smem + B128_QTILE + (t & 1) * 32768 + (16 * w) * 128;
+        const unsigned dst = smem_lds + B128_QTILE + (t & 1) * 32768 + (16 * w) * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(dst + pl * 8192 + j * 1024), 16, dma_vq[j] + pl * 128, sq, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(dst + 16384 + pl * 8192 + j * 1024), 16, dma_vdo[j] + pl * 128, sdo, 0, 0);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst + pl * 8192 + j * 1024), "v"(dma_vq[j] + pl * 128), "s"(rq_w), "s"(sq) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst + 16384 + pl * 8192 + j * 1024), "v"(dma_vdo[j] + pl * 128), "s"(rdo_w), "s"(sdo) : "memory");
             }
-        if (tid < 128) {
-            int qi = q0 + (tid & 63);
-            const bool ok = qi < p.S;
-            qi = ok ? qi : p.S - 1;
-            const float v = (tid < 64) ? lse_b[qi] * c_inv : -dl_b[qi];
-            *(float*)(smem + B128_STAT + (t & 1) * 512 + tid * 4) = ok ? v : 0.f;
-        }
+        int qi = q0 + (tid & 63);
+        gstat_ok = qi < p.S;
+        qi = gstat_ok ? qi : p.S - 1;
+        gstat = stat_src[qi];                             // used (and therefore waited for) only in stage_finish
+    };
+    auto stage_finish = [&](int t, bool all) {            // before the barrier that publishes tile t
+        if (tid < 128) *(float*)(smem + B128_STAT + (t & 1) * 512 + tid * 4) = gstat_ok ? gstat * stat_mul : 0.f;
+        if (all) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x8F70);          // vmcnt(32): this wave's 32 atomics of the previous step may stay in flight
     };
 
     f32x16 dk_acc[2][2], dv_acc[2][2];                    // [plane][d-tile]
@@ -339,10 +358,11 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
     const float sc = p.scale_log2;
     const int nsteps = (p.S + 63) / 64;
     stage(0);
+    stage_finish(0, true);
     __syncthreads();
+    stage(1);                                             // (past the end: zeros)
     for (int t = 0; t < nsteps; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nsteps) stage(t + 1);
         const char* tile = smem + B128_QTILE + buf * 32768;          // Q planes at +0, +8192; dO planes at +16384, +24576
         const float* lsel = (const float*)(smem + B128_STAT + buf * 512);
         char* dsimg = smem + B128_DSIMG + buf * 16384;
@@ -395,7 +415,9 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                 *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
             }
         }
+        stage_finish(t + 1, t == 0);
         __syncthreads();
+        stage(t + 2);
         // ---- dQ: one 32 x 32 tile per plane and wave over all 128 keys ----
         const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
 #pragma unroll

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from vt355 import ops
+from vt355 import ops          # VT355_LIB=<path> selects another build of the library (ablations)
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 B, H, hd = 1, 24, 128
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 10456

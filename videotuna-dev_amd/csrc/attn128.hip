@@ -20,6 +20,9 @@ struct Attn128Params {
 };
 
 #define A128_NEG (-1.0e30f)
+#ifndef A128_ABL_NOATOM
+#define A128_ABL_NOATOM 0
+#endif
 
 __device__ __forceinline__ bf16x8 a128_tr_pair(const char* p0, const char* p1) {
     short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(p0));
@@ -431,9 +434,15 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                 const bf16x8 fb = a128_tr_pair(smem + B128_KIMG + pl * 16384 + s3 * 2048 + trQB[0], smem + B128_KIMG + pl * 16384 + s3 * 2048 + trQB[1]);
                 dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, dq_acc, 0, 0, 0);
             }
+#if A128_ABL_NOATOM       // timing-only ablation (results wrong): what the dQ atomics cost
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
+            (void)soff; (void)dq_rowb; (void)dq_voff;
+#else
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff + pl * 256, soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
+#endif
         }
     }
     // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----

@@ -241,3 +241,39 @@ def test_attn128_matches_dense_attention(dev, B, S, H, lens):
     if kv is not None:
         for b in range(B):
             assert dqkv[b, lens[b]:, C:].abs().max().item() == 0 if lens[b] < S else True
+
+
+def test_attn128_full_length_properties(dev):
+    """vt_attn128 at HunyuanVideo's sequence (10 200 image + 256 text tokens, 24 heads would be 3.4 TFLOP: 4 heads here), where a dense
+    reference does not fit: size-independent properties of attention and its gradient --
+      * every output row is a convex combination of V rows: |o| <= max |v| per head and channel;
+      * sum_i q_i . dq_i == sum_j k_j . dk_j per (sample, head)  (the scores are bilinear in q and k);
+      * the backward is linear in dO: bwd(a g1 + g2) == a bwd(g1) + bwd(g2);
+      * keys past the valid length get exactly zero dK / dV."""
+    from vt355 import ops
+    gen = torch.Generator(device=dev).manual_seed(8)
+    B, S, H = 1, 10456, 4
+    C = H * 128
+    qkv = (0.5 * torch.randn(B, S, 3 * C, device=dev, generator=gen)).to(BF)
+    q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    kv = torch.tensor([S - 56], dtype=torch.int32, device=dev)
+    o = torch.empty(B, S, C, dtype=BF, device=dev); lse = torch.empty(B, H, S, device=dev)
+    scale = 128 ** -0.5
+    ops.attn128_fwd(q, k, v, o, lse, H, scale, kv_len=kv)
+    vmax = v[:, :S - 56].float().abs().amax(1, keepdim=True)
+    assert (o.float().abs() <= vmax * 1.01 + 1e-3).all() and torch.isfinite(lse[:, :, :S - 56]).all()
+
+    def bwd(g):
+        dq = torch.empty(B, S, C, device=dev); d = torch.empty(B, S, 2 * C, dtype=BF, device=dev)
+        ops.attn128_bwd(q, k, v, o, g, lse, dq, d[:, :, :C], d[:, :, C:], H, scale, kv_len=kv)
+        return dq, d[:, :, :C].float(), d[:, :, C:].float()
+    g1 = torch.randn(B, S, C, device=dev, generator=gen).to(BF); g2 = torch.randn(B, S, C, device=dev, generator=gen).to(BF)
+    g1[:, S - 56:] = 0; g2[:, S - 56:] = 0
+    dq1, dk1, dv1 = bwd(g1)
+    lhs = (q.float() * dq1).view(B, S, H, 128).sum((1, 3)); rhs = (k.float() * dk1).view(B, S, H, 128).sum((1, 3))
+    assert ((lhs - rhs).abs() <= 2e-2 * lhs.abs().clamp_min(1.0)).all(), (lhs, rhs)
+    assert dk1[:, S - 56:].abs().max().item() == 0 and dv1[:, S - 56:].abs().max().item() == 0
+    dq2, dk2, dv2 = bwd(g2)
+    dq3, dk3, dv3 = bwd((2 * g1.float() + g2.float()).to(BF))
+    for a, b_ in ((dq3, 2 * dq1 + dq2), (dk3, 2 * dk1 + dk2), (dv3, 2 * dv1 + dv2)):
+        assert _rel(a, b_) < 2e-2

@@ -271,11 +271,19 @@ def bench_hunyuan(args):
     assert world == args.gpus == 1, "the HunyuanVideo line is single-GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    nd, ns = (4, 8) if args.layers == 30 else (max(1, args.layers // 3), max(1, args.layers - args.layers // 3))
+    lora = args.mode == "lora" and args.layers == 30 and os.environ.get("VT_HY_FULLFT") is None
+    if lora:
+        nd, ns = 20, 40               # the whole trunk: frozen block weights (25.7 GB bf16) + rank-4 adapters, as the shipped recipe trains
+    else:
+        nd, ns = (4, 8) if args.layers == 30 else (max(1, args.layers // 3), max(1, args.layers - args.layers // 3))
     D, H, Li, Lt = 3072, 24, 10200, 256
     B = args.micro_batch if args.micro_batch is not None else 1
-    model = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=nd, mm_single_blocks_depth=ns).to(dev).init_weights(11)
-    ts = model.enable_training()
+    model = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=nd, mm_single_blocks_depth=ns, lora_rank=4 if lora else 0).to(dev).init_weights(11)
+    if lora:
+        model.lora.init_weights(12, zero_b=False)
+        ts = model.enable_lora_training()
+    else:
+        ts = model.enable_training()
     opt = FusedAdamW(ts.params, lr=1e-5, fullft_state=ts)
     g = torch.Generator(device=dev).manual_seed(20230211)
     ang = torch.rand(Li, 64, device=dev, generator=g) * 6.28
@@ -311,15 +319,22 @@ def bench_hunyuan(args):
     # per block forward: linears + attention 4 S^2 d; double: img+txt streams (qkv, proj, fc1, fc2 = 24 S d^2 over both streams); single: linear1 + linear2
     fwd_double = 24.0 * S * D * D + 4.0 * S * S * D
     fwd_single = 2.0 * S * D * (3 * D + 4 * D) + 2.0 * S * (D + 4 * D) * D + 4.0 * S * S * D
-    step_tf = 3.0 * B * (nd * fwd_double + ns * fwd_single) / 1e12
+    att = 4.0 * S * S * D
+    if lora:    # forward + backward without the frozen weights' dW: linears 2x, attention 3x
+        step_tf = B * (nd * (2.0 * (fwd_double - att) + 3.0 * att) + ns * (2.0 * (fwd_single - att) + 3.0 * att)) / 1e12
+    else:
+        step_tf = 3.0 * B * (nd * fwd_double + ns * fwd_single) / 1e12
     lv = [float(x) for x in torch.stack(losses[-args.steps:]).cpu()]
-    print(json.dumps({"metric": "finetune samples/sec, HunyuanVideo block trunk (4 double + 8 single of 20 + 40) 544x960x17f full-FT bf16",
+    print(json.dumps({"metric": ("finetune samples/sec, HunyuanVideo block trunk (all 20 double + 40 single blocks) 544x960x17f LoRA r=4 bf16" if lora else
+                                 "finetune samples/sec, HunyuanVideo block trunk (%d double + %d single of 20 + 40) 544x960x17f full-FT bf16" % (nd, ns)),
                       "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                       "data": "synthetic",
                       "config": {"workload": "HunyuanVideo MMDoubleStreamBlock / MMSingleStreamBlock trunk (configs[4] family, NOT the headline config and "
                                              f"NOT the whole model): {nd} double + {ns} single blocks, image tokens {Li} + text {Lt} (valid {tv.tolist()}), "
-                                             "d 3072, 24 x 128, all block weights trained, flow-matching loss",
+                                             "d 3072, 24 x 128, " + ("block weights frozen, rank-4 adapters on the image stream's q / k / v / out projections trained (configs/007 recipe), "
+                                                                  if lora else "all block weights trained, ") + "flow-matching loss",
+                                 "mode": "lora" if lora else "fullft",
                                  "micro_batch": B, "double_blocks": nd, "single_blocks": ns, "weights": "seeded random init"},
                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1), "step_tflops_algorithmic": step_tf * args.steps / elapsed,
                       "kernels": kern, "loss_first": lv[0], "loss_last": lv[-1]}), flush=True)

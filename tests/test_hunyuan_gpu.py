@@ -277,3 +277,65 @@ def test_attn128_full_length_properties(dev):
     dq3, dk3, dv3 = bwd((2 * g1.float() + g2.float()).to(BF))
     for a, b_ in ((dq3, 2 * dq1 + dq2), (dk3, 2 * dk1 + dk2), (dv3, 2 * dv1 + dv2)):
         assert _rel(a, b_) < 2e-2
+
+
+def test_lora_blocks_train_step_matches_oracle(dev):
+    """LoRA mode (rank-4 adapters on img_attn_qkv / img_attn_proj / linear1's q, k, v rows; block weights frozen): one double + one single
+    block, forward and every adapter gradient + input gradients vs the fp64 oracle run on the effective weights W + scaling * B A
+    (differentiated w.r.t. A and B by autograd); the frozen weights receive no gradient buffer at all"""
+    import hunyuan_oracle as HO
+    from vt355.hunyuan import HunyuanBlocks
+    from vt355.optim import FusedAdamW
+    g, T = _golden()
+    D, H, r = 256, 2, 4
+    m = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=1, mm_single_blocks_depth=1, lora_rank=r, lora_alpha=2.0)
+    P = {**HO.init(HO.double_block_shapes(D, H, pre="double_blocks.0."), 1), **HO.init(HO.single_block_shapes(D, H, pre="single_blocks.0."), 2)}
+    m.load_state_dict(P, strict=False)
+    m.lora.init_weights(5, zero_b=False)
+    m.to(dev)
+    ts = m.enable_lora_training()
+    assert m.train_state is None and ts.numel == m.lora.numel
+    tv = T("txt_valid")
+    img, txt, vec = [T(k).to(BF) for k in ("img", "txt", "vec")]
+    Li, Lt = img.shape[1], txt.shape[1]
+    xi, xt, xv = [t.to(dev).requires_grad_(True) for t in (img, txt, vec)]
+    out = m(xi, xt, xv, tv.to(dev), (T("cos").to(dev), T("sin").to(dev)))
+    gx = T("s_gx").to(BF)
+    out.backward(gx.to(dev))
+    # oracle on effective weights
+    base = {k: v.detach().float().cpu().double() for k, v in m.named_parameters() if not k.startswith("lora.")}
+    ad = {k[5:]: v.detach().float().cpu().double().requires_grad_(True) for k, v in m.named_parameters() if k.startswith("lora.")}
+    s = m.lora.scaling
+    Pe = dict(base)
+    def eff(mod, rows_of):
+        w = base[mod + ".weight"].clone()
+        for j, t in enumerate(m.lora.sites[mod]):
+            dot = "." + t if t else ""
+            w[j * D:(j + 1) * D] = w[j * D:(j + 1) * D] + s * ad[f"{mod}.lora_B{dot}.weight"] @ ad[f"{mod}.lora_A{dot}.weight"]
+        return w
+    for mod in m.lora.sites:
+        Pe[mod + ".weight"] = eff(mod, None)
+    ri, rt, rv = [t.double().requires_grad_(True) for t in (img, txt, vec)]
+    io, to = HO.double_block(ri, rt, rv, Pe, "double_blocks.0.", H, tv, T("cos").double(), T("sin").double())
+    xo = HO.single_block(torch.cat([io, to], 1), rv, Pe, "single_blocks.0.", H, Lt, tv, T("cos").double(), T("sin").double())
+    (xo * gx.double()).sum().backward()
+    vm = (gx.abs().sum(-1, keepdim=True) > 0).double()
+    e = _rel(out.double().cpu() * vm, xo * vm)
+    print(f"[hunyuan lora] fwd rel-L2 {e:.3e}")
+    assert e < 1e-2
+    assert _rel(xi.grad, ri.grad) < 3e-2 and _rel(xt.grad.double().cpu() * (T('d_gt').abs().sum(-1, keepdim=True) > 0), rt.grad * (T('d_gt').abs().sum(-1, keepdim=True) > 0)) < 3e-2
+    worst = 0.0
+    for n in m.lora.shapes:
+        gd = m.lora._view(ts.grad, n).detach().double().cpu()
+        gr = ad[n].grad
+        e = (gd - gr).norm().item() / max(gr.norm().item(), 1e-12)
+        cos = torch.nn.functional.cosine_similarity(gd.flatten(), gr.flatten(), dim=0).item()
+        worst = max(worst, e)
+        assert cos > 0.98 and e < 0.2, (n, e, cos)
+    print(f"[hunyuan lora] adapter grads worst rel-L2 {worst:.3e}")
+    opt = FusedAdamW(ts.params, lr=1e-3, fullft_state=ts)
+    before = ts.flat.clone()
+    opt.step()
+    assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
+    out2 = m(xi.detach(), xt.detach(), xv.detach(), tv.to(dev), (T("cos").to(dev), T("sin").to(dev)))     # repacked adapters are used
+    assert (out2.float() - out.float()).abs().max().item() > 0

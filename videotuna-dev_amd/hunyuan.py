@@ -48,12 +48,62 @@ def _single_shapes(D, H, ratio, pre):
             pre + "modulation.linear.weight": (3 * D, D), pre + "modulation.linear.bias": (3 * D,)}
 
 
+class _XVar(_Var):
+    """an activation that lives in the first D columns of an extended buffer (input of a LoRA'd Linear)"""
+    __slots__ = ("ext",)
+
+    def __init__(self, d, ext):
+        super().__init__(d)
+        self.ext = ext
+
+
+EXT = 64          # K-extension columns of a LoRA'd Linear: x_ext = [x | x A^T (3 r <= 64 columns) | 0], W_ext = [W | scaling * B | 0]
+
+
+class _HYLora(FlatParamModule):
+    """rank-r adapters on the image stream's attention projections, the modules the shipped recipe targets (configs/007_hunyuanvideo/
+    hunyuanvideo_t2v_diffuser_lora.yaml:59-64: r 4, alpha 1, target_modules to_q / to_k / to_v / to_out.0 of diffusers' attention): here the
+    q / k / v row blocks of ``double_blocks.N.img_attn_qkv`` and of ``single_blocks.N.linear1`` and ``double_blocks.N.img_attn_proj``.
+    Parameter names: ``<module>.lora_A.{q,k,v}.weight [r, D]``, ``<module>.lora_B.{q,k,v}.weight [D, r]`` (proj: no q/k/v level)."""
+
+    def __init__(self, D: int, n_double: int, n_single: int, r: int, alpha: float):
+        super().__init__()
+        if 3 * r > EXT:
+            raise ValueError(f"rank {r}: three adapters must fit the {EXT} extension columns")
+        self.r, self.scaling, self.D = r, alpha / r, D
+        sh: Dict[str, tuple] = {}
+        self.sites: Dict[str, list] = {}            # module name -> adapter tags
+        for i in range(n_double):
+            self.sites[f"double_blocks.{i}.img_attn_qkv"] = ["q", "k", "v"]
+            self.sites[f"double_blocks.{i}.img_attn_proj"] = [""]
+        for i in range(n_single):
+            self.sites[f"single_blocks.{i}.linear1"] = ["q", "k", "v"]
+        for mod, tags in self.sites.items():
+            for t in tags:
+                dot = "." + t if t else ""
+                sh[f"{mod}.lora_A{dot}.weight"] = (r, D)
+                sh[f"{mod}.lora_B{dot}.weight"] = (D, r)
+        self._setup_flat(sh)
+
+    def init_weights(self, seed: int = 0, zero_b: bool = True):
+        """peft's default: A random, B zero (the adapter starts as the identity); zero_b=False for tests"""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for n, p in self._plist.items():
+                if ".lora_A" in n:
+                    p.copy_((torch.randn(self.shapes[n], generator=g) * self.D ** -0.5).to(p.device, BF16))
+                else:
+                    p.copy_((torch.zeros(self.shapes[n]) if zero_b else torch.randn(self.shapes[n], generator=g) * 0.05).to(p.device, BF16))
+        self._packed = None
+        return self
+
+
 class HunyuanBlocks(FlatParamModule):
     """double_blocks.{i}.* / single_blocks.{i}.* of HYVideoDiffusionTransformer (models.py:396-...): hidden_size 3072, 24 heads x 128,
     20 + 40 blocks in HunyuanVideo-T2V"""
 
     def __init__(self, hidden_size: int = 3072, heads_num: int = 24, mlp_width_ratio: float = 4.0, mm_double_blocks_depth: int = 20,
-                 mm_single_blocks_depth: int = 40, fp8: bool = False):
+                 mm_single_blocks_depth: int = 40, fp8: bool = False, lora_rank: int = 0, lora_alpha: float = 1.0):
         super().__init__()
         if hidden_size // heads_num != 128 or hidden_size % 128:
             raise ValueError("HunyuanVideo heads are 128 wide")
@@ -65,6 +115,8 @@ class HunyuanBlocks(FlatParamModule):
         for i in range(mm_single_blocks_depth):
             sh.update(_single_shapes(hidden_size, heads_num, mlp_width_ratio, f"single_blocks.{i}."))
         self._setup_flat(sh)
+        # LoRA mode: the block weights stay frozen (no fp32 master, no gradients, no dW GEMMs); only the adapters train
+        self.lora = _HYLora(hidden_size, mm_double_blocks_depth, mm_single_blocks_depth, lora_rank, lora_alpha) if lora_rank > 0 else None
 
     def init_weights(self, seed: int = 0):
         g = torch.Generator().manual_seed(seed)
@@ -77,14 +129,24 @@ class HunyuanBlocks(FlatParamModule):
                     w = torch.randn(s, generator=g) * (0.7 / s[1] ** 0.5)
                 p.copy_(w.to(p.device, BF16))
         self._packed = None
+        if self.lora is not None:
+            self.lora.init_weights(seed + 1)
         return self
+
+    def enable_lora_training(self):
+        """training state of the adapters only (hand it to FusedAdamW(ts.params, fullft_state=ts)); the block weights stay frozen"""
+        if self.lora is None:
+            raise RuntimeError("construct HunyuanBlocks(lora_rank=r) first")
+        self.requires_grad_(False)
+        self.lora.requires_grad_(True)
+        return self.lora.enable_training()
 
     def forward(self, img, txt, vec, txt_valid, freqs_cis=None):
         """img [B, Li, D], txt [B, Lt, D], vec [B, D] bf16; txt_valid int [B] valid text tokens; freqs_cis = (cos, sin) fp32 [Li, 128]
         -> x [B, Li + Lt, D] = [image; text] after every double and single block (models.py: HYVideoDiffusionTransformer.forward trunk)"""
         if not img.is_cuda:
             raise RuntimeError("vt355 HunyuanBlocks runs only on an MI355X device (no CPU fallback)")
-        if torch.is_grad_enabled() and self.train_state is not None:
+        if torch.is_grad_enabled() and (self.train_state is not None or (self.lora is not None and self.lora.train_state is not None)):
             anchor = torch.zeros(1, device=img.device, requires_grad=True)
             return _HYFn.apply(anchor, self, img, txt, vec, txt_valid, freqs_cis)
         return _HYRun(self, save=False).forward(img, txt, vec, txt_valid, freqs_cis)
@@ -116,11 +178,39 @@ def _packed_hy(model: HunyuanBlocks) -> SimpleNamespace:
         for n, shp in model.shapes.items():
             if n.endswith(".weight") and len(shp) == 2:
                 w = model.flat(fb, n)
-                if model.train_state is not None:
+                lora_site = model.lora is not None and n[:-7] in model.lora.sites       # its transposed operand is the extended one (_packed_lora)
+                if (model.train_state is not None or (model.lora is not None and model.lora.train_state is not None)) and not lora_site:
                     P.wt[n] = w.t().contiguous()
                 if model.fp8 and n.endswith("_attn_qkv.weight"):    # E4M3 copy + per-tensor scale (fp8_optimization.py:55-64)
                     P.q[n] = ops.quantize_fp8(w)
     model._packed, model._packed_version = P, ver
+    return P
+
+
+def _packed_lora(model: HunyuanBlocks) -> SimpleNamespace:
+    """per adapted Linear: W_ext [N, D + EXT] = [W | scaling B (block structure: adapter j in columns j r .. of its row block) | 0], its
+    transpose, A3 [EXT, D] (rows j r ..: A_j) and its transpose -- the K-extension of DESIGN 3 "LoRA as a K-extension", so that
+    y = [x | x A3^T] W_ext^T is ONE GEMM with the Linear's own epilogue.  Rebuilt when the adapters change (optimizer step)."""
+    L = model.lora
+    ver = -1 if L.train_state is None else L.train_state.version
+    if L._packed is not None and L._packed_version == ver:
+        return L._packed
+    P = SimpleNamespace(wext={}, wtext={}, a3={}, a3t={})
+    D, r = L.D, L.r
+    with torch.no_grad():
+        for mod, tags in L.sites.items():
+            w = model.flat(model.flat_bf16, mod + ".weight")
+            nrows = D * len(tags)                                       # linear1: only its first 3 D rows (q | k | v) are adapted
+            wext = torch.zeros(nrows, D + EXT, dtype=BF16, device=w.device)
+            wext[:, :D] = w[:nrows]
+            a3 = torch.zeros(EXT, D, dtype=BF16, device=w.device)
+            for j, t in enumerate(tags):
+                dot = "." + t if t else ""
+                wext[j * D:(j + 1) * D, D + j * r:D + (j + 1) * r] = (L._plist[f"{mod}.lora_B{dot}.weight"].float() * L.scaling).to(BF16)
+                a3[j * r:(j + 1) * r] = L._plist[f"{mod}.lora_A{dot}.weight"]
+            P.wext[mod], P.wtext[mod] = wext, wext.t().contiguous()
+            P.a3[mod], P.a3t[mod] = a3, a3.t().contiguous()
+    L._packed, L._packed_version = P, ver
     return P
 
 
@@ -132,28 +222,143 @@ class _HYRun(_STRun):
         self.ts = model.train_state
         self.tape = []
         self.dev = model.device
+        self.lora = model.lora
+        self.LP = _packed_lora(model) if model.lora is not None else None
+        self.lts = None if model.lora is None else model.lora.train_state
+        self._dummy = torch.zeros(256, dtype=F32, device=self.dev)       # sink of parameter gradients nobody trains (frozen q / k norms)
+
+    # ---- frozen block weights (LoRA mode: self.ts is None): no gradient buffers, no dW GEMMs ----
+    def G(self, name):
+        return None if self.ts is None else self.m.flat(self.ts.grad, name)
+
+    def dW(self, dy, x, target):
+        if target is not None:
+            super().dW(dy, x, target)
+
+    def colsum(self, g, name, D):
+        if self.ts is not None:
+            ops.group_colsum(g, self.G(name), D=D)
+
+    def ext(self, M):
+        """activation buffer of an adapted Linear's input: [M, D + EXT], the Linear reads all of it, producers write [:, :D]"""
+        return self.E(M, self.m.hidden_size + EXT)
+
+    def lora_linear(self, xe, mod: str, bias, y=None, **epi):
+        """y = [x | x A3^T] W_ext^T + bias (+ epilogue) for the adapted Linear `mod`; xe: ext buffer whose [:, :D] holds x.  Returns
+        (y, backward(g) -> dx [M, D]) -- the caller decides what g is (gated or not) and where dx goes."""
+        D = self.m.hidden_size
+        M = xe.shape[0]
+        wext, a3 = self.LP.wext[mod], self.LP.a3[mod]
+        ops.gemm(xe[:, :D], a3, xe[:, D:], None, K=D)                  # t = x A3^T into the extension columns
+        if y is None:
+            y = self.E(M, wext.shape[0])
+        ops.gemm(xe, wext, y, bias, **epi)
+
+        def backward(g):
+            L, r = self.lora, self.lora.r
+            dxe = self.E(M, D + EXT)
+            ops.gemm(g, self.LP.wtext[mod], dxe, None)                  # [dx | dt] = g W_ext
+            if self.lts is not None:
+                db = torch.zeros(wext.shape[0], EXT, dtype=F32, device=self.dev)
+                ops.linear_dw(g, xe[:, D:], db, accumulate=False)       # d(scaling B) blocks = g^T t
+                da = torch.zeros(EXT, D, dtype=F32, device=self.dev)
+                ops.linear_dw(dxe[:, D:], xe[:, :D], da, accumulate=False)   # dA3 = dt^T x
+                for j, t in enumerate(L.sites[mod]):
+                    dot = "." + t if t else ""
+                    L.flat(self.lts.grad, f"{mod}.lora_B{dot}.weight").add_(db[j * D:(j + 1) * D, j * r:(j + 1) * r], alpha=L.scaling)
+                    L.flat(self.lts.grad, f"{mod}.lora_A{dot}.weight").add_(da[j * r:(j + 1) * r])
+            dx = self.E(M, D)
+            ops.gemm(dxe[:, D:], self.LP.a3t[mod], dx, None, epilogue=EPI_GATED_RES, residual=dxe[:, :D])     # dx + dt A3
+            return dx
+        return y, backward
 
     def linear(self, x: _Var, wname: str, bname, residual=None, wspan=None, out=None) -> _Var:
-        """block Linear without epilogue: with fp8=True its FORWARD product runs on the fp8 matrix cores (activation quantised per tensor
-        here, weight copy + scale from _packed_hy); the backward is the bf16 one of vt355.unet._Run.linear"""
-        if not (self.m.fp8 and wname in self.P.q and residual is None and wspan is None):
-            return super().linear(x, wname, bname, residual, wspan, out)
+        """block Linear without epilogue (the qkv projections).  Adapted module (LoRA): one GEMM over the K-extended operands.  fp8=True: the
+        FORWARD product on the fp8 matrix cores (activation quantised per tensor here, weight copy + scale from _packed_hy).  Parameter
+        gradients only when the block weights train."""
+        assert residual is None and wspan is None and out is None
+        mod = wname[:-7]
         M = x.d.shape[0]
-        wq, sw = self.P.q[wname]
-        y = out if out is not None else self.E(M, wq.shape[0])
-        xq, sa = ops.quantize_fp8(x.d)
-        ops.gemm_fp8(xq, wq, y, sa, sw, None if bname is None else self.W(bname))
+        b = None if bname is None else self.W(bname)
+        if self.lora is not None and mod in self.lora.sites:
+            y, bw = self.lora_linear(x.ext, mod, b)
+            yv = _Var(y)
+            if self.save:
+                def bwd_linear_lora():
+                    self.colsum(yv.g, bname, y.shape[1])
+                    self.acc(x, bw(yv.g))
+                self.tape.append(bwd_linear_lora)
+            return yv
+        w = self.W(wname)
+        y = self.E(M, w.shape[0])
+        if self.m.fp8 and wname in self.P.q:
+            wq, sw = self.P.q[wname]
+            xq, sa = ops.quantize_fp8(x.d)
+            ops.gemm_fp8(xq, wq, y, sa, sw, b)
+        else:
+            ops.gemm(x.d, w, y, b)
         yv = _Var(y)
         if self.save:
-            def bwd_linear_fp8():
+            def bwd_linear():
                 g = yv.g
-                if bname is not None:
-                    ops.group_colsum(g, self.G(bname), D=wq.shape[0])
+                self.colsum(g, bname, w.shape[0])
                 self.dW(g, x.d, self.G(wname))
-                dx = self.E(M, wq.shape[1])
+                dx = self.E(M, w.shape[1])
                 ops.gemm(g, self.P.wt[wname], dx, None)
                 self.acc(x, dx)
-            self.tape.append(bwd_linear_fp8)
+            self.tape.append(bwd_linear)
+        return yv
+
+    def ln_mod(self, x: _Var, shift, scale, bstride: int, rows_per_sample: int, dshift, dscale, dbstride: int, ext: bool = False) -> _Var:
+        """as _STRun.ln_mod; ext=True: the result is written into the first D columns of an extended buffer (input of an adapted Linear)"""
+        if not ext:
+            return super().ln_mod(x, shift, scale, bstride, rows_per_sample, dshift, dscale, dbstride)
+        M, D = x.d.shape
+        buf = self.ext(M)
+        y = buf[:, :D]
+        mean, rstd = self.E(M, dt=F32), self.E(M, dt=F32)
+        ops.ln_modulate_fwd(x.d, y, None, None, (shift, scale, shift, scale, bstride), mean, rstd, D, rows_per_sample, 0, 1e-6)
+        yv = _XVar(y, buf)
+        if self.save:
+            def bwd_ln_mod_ext():
+                g = yv.g
+                ops.group_colsum(g, dshift, y=x.d, out2=dscale, mean=mean, rstd=rstd, D=D, S=rows_per_sample, St=0, grouped=True,
+                                 o_bstride=dbstride, o_segstride=0)
+                dx = self.E(M, D)
+                ops.ln_modulate_bwd(g, x.d, mean, rstd, None, (scale, scale, bstride), x.g, dx, D, rows_per_sample, 0)
+                x.g = dx
+            self.tape.append(bwd_ln_mod_ext)
+        return yv
+
+    def mlp(self, x: _Var, pre: str, residual=None, gate=None, dgate=None) -> _Var:
+        """_STRun.mlp with the parameter gradients behind the frozen-weights switch"""
+        M = x.d.shape[0]
+        w1, w2 = self.W(pre + "fc1.weight"), self.W(pre + "fc2.weight")
+        H4, Dout = w1.shape[0], w2.shape[0]
+        u = self.E(M, H4); ga = self.E(M, H4)
+        ops.gemm(x.d, w1, ga, self.W(pre + "fc1.bias"), epilogue=EPI_BIAS_GELU, pre_act_out=u)
+        y = self.E(M, Dout)
+        branch = self.E(M, Dout) if self.save else None
+        ops.gemm(ga, w2, y, self.W(pre + "fc2.bias"), epilogue=EPI_GATED_RES, residual=residual.d, gate_txt=gate[0], gate_vid=gate[0],
+                 gate_bstride=gate[1], S=gate[2], St=0, pre_act_out=branch)
+        yv = _Var(y)
+        if self.save:
+            def bwd_mlp():
+                g_ = yv.g
+                self.acc(residual, g_)
+                ops.group_colsum(g_, None, y=branch, out2=dgate, D=Dout, S=gate[2], St=0, grouped=True, o_bstride=gate[1], o_segstride=0)
+                gg = self.E(M, Dout)
+                ops.gate_mul(g_, gg, gate[0], gate[0], gate[1], Dout, gate[2], 0)
+                self.colsum(gg, pre + "fc2.bias", Dout)
+                self.dW(gg, ga, self.G(pre + "fc2.weight"))
+                du = self.E(M, H4)
+                ops.gemm(gg, self.P.wt[pre + "fc2.weight"], du, None, epilogue=EPI_DGELU, pre_act_in=u)
+                self.colsum(du, pre + "fc1.bias", H4)
+                self.dW(du, x.d, self.G(pre + "fc1.weight"))
+                dx = self.E(M, w1.shape[1])
+                ops.gemm(du, self.P.wt[pre + "fc1.weight"], dx, None)
+                self.acc(x, dx)
+            self.tape.append(bwd_mlp)
         return yv
 
     def modulation(self, sv: _Var, pre: str, n: int):
@@ -169,26 +374,35 @@ class _HYRun(_STRun):
         return mod, dmod
 
     def glinear(self, x: _Var, wname: str, bname: str, residual: _Var, gate, dgate, rps: int, bs: int) -> _Var:
-        """y = residual + gate[b] * (x W^T + b)   (apply_gate, modulate_layers.py:49-66)"""
+        """y = residual + gate[b] * (x W^T + b)   (apply_gate, modulate_layers.py:49-66); adapted module: over the K-extended operands"""
+        mod = wname[:-7]
+        adapted = self.lora is not None and mod in self.lora.sites
         w = self.W(wname)
-        M = x.d.shape[0]
-        y = self.E(M, w.shape[0])
-        branch = self.E(M, w.shape[0]) if self.save else None
-        ops.gemm(x.d, w, y, self.W(bname), epilogue=EPI_GATED_RES, residual=residual.d, gate_txt=gate, gate_vid=gate, gate_bstride=bs, S=rps, St=0,
-                 pre_act_out=branch)
+        M, N = x.d.shape[0], w.shape[0]
+        y = self.E(M, N)
+        branch = self.E(M, N) if self.save else None
+        epi = dict(epilogue=EPI_GATED_RES, residual=residual.d, gate_txt=gate, gate_vid=gate, gate_bstride=bs, S=rps, St=0, pre_act_out=branch)
+        bw = None
+        if adapted:
+            y, bw = self.lora_linear(x.ext, mod, self.W(bname), y=y, **epi)
+        else:
+            ops.gemm(x.d, w, y, self.W(bname), **epi)
         yv = _Var(y)
         if self.save:
             def bwd_glinear():
                 g_ = yv.g
                 self.acc(residual, g_)
-                ops.group_colsum(g_, None, y=branch, out2=dgate, D=w.shape[0], S=rps, St=0, grouped=True, o_bstride=bs, o_segstride=0)
-                gg = self.E(M, w.shape[0])
-                ops.gate_mul(g_, gg, gate, gate, bs, w.shape[0], rps, 0)
-                ops.group_colsum(gg, self.G(bname), D=w.shape[0])
-                self.dW(gg, x.d, self.G(wname))
-                dx = self.E(M, w.shape[1])
-                ops.gemm(gg, self.P.wt[wname], dx, None)
-                self.acc(x, dx)
+                ops.group_colsum(g_, None, y=branch, out2=dgate, D=N, S=rps, St=0, grouped=True, o_bstride=bs, o_segstride=0)
+                gg = self.E(M, N)
+                ops.gate_mul(g_, gg, gate, gate, bs, N, rps, 0)
+                self.colsum(gg, bname, N)
+                if adapted:
+                    self.acc(x, bw(gg))
+                else:
+                    self.dW(gg, x.d, self.G(wname))
+                    dx = self.E(M, w.shape[1])
+                    ops.gemm(gg, self.P.wt[wname], dx, None)
+                    self.acc(x, dx)
             self.tape.append(bwd_glinear)
         return yv
 
@@ -202,7 +416,9 @@ class _HYRun(_STRun):
         if self.save:
             def bwd_qkv_to_joint():
                 dq = self.E(M, qkv.d.shape[1])
-                ops.qk_rmsnorm_rope128_bwd(djoint_ref[0], qkv.d, dq, gq, gk, rstd, self.G(pre_q), self.G(pre_k), H, L, Lj, off, rope)
+                frozen = self.ts is None
+                ops.qk_rmsnorm_rope128_bwd(djoint_ref[0], qkv.d, dq, gq, gk, rstd, self._dummy[:128] if frozen else self.G(pre_q),
+                                           self._dummy[128:] if frozen else self.G(pre_k), H, L, Lj, off, rope)
                 qkv.g = dq
             self.tape.append(bwd_qkv_to_joint)
 
@@ -242,7 +458,8 @@ class _HYRun(_STRun):
             mod, dmod = self.modulation(sv, pre + s + "_mod", 6)
             sl = lambda k, buf=mod: buf[:, k * D:(k + 1) * D]
             dsl = (lambda k, buf=dmod: buf[:, k * D:(k + 1) * D]) if self.save else (lambda k: None)
-            xm = self.ln_mod(x, sl(0), sl(1), bs, L, dsl(0), dsl(1), bs)
+            adapted = self.lora is not None and s == "img"
+            xm = self.ln_mod(x, sl(0), sl(1), bs, L, dsl(0), dsl(1), bs, ext=adapted)
             qkv = self.linear(xm, pre + s + "_attn_qkv.weight", pre + s + "_attn_qkv.bias")
             streams[s] = (x, L, off, sl, dsl, qkv, rp)
         # the backward of the scatter must run AFTER the attention's backward has produced the joint gradient: push order = forward order
@@ -254,8 +471,12 @@ class _HYRun(_STRun):
         outs = {}
         for s in ("img", "txt"):
             x, L, off, sl, dsl, qkv, rp = streams[s]
-            a = o.view(B, Lj, C)[:, off:off + L].reshape(B * L, C)                  # this stream's rows of the joint output (a copy)
-            av = _Var(a)
+            if self.lora is not None and s == "img":                                 # input of the adapted projection: extended buffer
+                ae = self.ext(B * L)
+                ae.view(B, L, C + EXT)[:, :, :C].copy_(o.view(B, Lj, C)[:, off:off + L])
+                av = _XVar(ae[:, :C], ae)
+            else:
+                av = _Var(o.view(B, Lj, C)[:, off:off + L].reshape(B * L, C))       # this stream's rows of the joint output (a copy)
             if self.save:
                 def bwd_split(av=av, off=off, L=L, ov=ov):
                     if ov.g is None:
@@ -276,10 +497,16 @@ class _HYRun(_STRun):
         mod, dmod = self.modulation(sv, pre + "modulation", 3)
         sl = lambda k: mod[:, k * D:(k + 1) * D]
         dsl = (lambda k: dmod[:, k * D:(k + 1) * D]) if self.save else (lambda k: None)
-        xm = self.ln_mod(x, sl(0), sl(1), bs, Lj, dsl(0), dsl(1), bs)
+        mod1 = pre + "linear1"
+        adapted = self.lora is not None and mod1 in self.lora.sites
+        xm = self.ln_mod(x, sl(0), sl(1), bs, Lj, dsl(0), dsl(1), bs, ext=adapted)
         w1, b1 = self.W(pre + "linear1.weight"), self.W(pre + "linear1.bias")
         qkv = self.E(M, 3 * D)
-        ops.gemm(xm.d, w1[:3 * D], qkv, b1[:3 * D])
+        bw1 = None
+        if adapted:
+            qkv, bw1 = self.lora_linear(xm.ext, mod1, b1[:3 * D], y=qkv)
+        else:
+            ops.gemm(xm.d, w1[:3 * D], qkv, b1[:3 * D])
         cat = self.E(M, D + M4)                                  # [attn | gelu(mlp)], read by linear2
         u = self.E(M, M4)
         ops.gemm(xm.d, w1[3 * D:], cat[:, D:], b1[3 * D:], epilogue=EPI_BIAS_GELU, pre_act_out=u)
@@ -291,11 +518,15 @@ class _HYRun(_STRun):
             def bwd_linear1():
                 du = catv.g[:, D:]                               # bwd_linear2 left d u = (g W2[:, D:]) * gelu'(u) in the mlp columns
                 dqkv = qkvv.g
-                gw, gb = self.G(pre + "linear1.weight"), self.G(pre + "linear1.bias")
-                ops.group_colsum(dqkv, gb[:3 * D], D=3 * D); ops.group_colsum(du, gb[3 * D:], D=M4)
-                self.dW(dqkv, xm.d, gw[:3 * D]); self.dW(du, xm.d, gw[3 * D:])
-                dx = self.E(M, D)
-                ops.gemm(dqkv, self._wt_rows(pre + "linear1.weight", 0, 3 * D), dx, None)
+                if self.ts is not None:
+                    gw, gb = self.G(pre + "linear1.weight"), self.G(pre + "linear1.bias")
+                    ops.group_colsum(dqkv, gb[:3 * D], D=3 * D); ops.group_colsum(du, gb[3 * D:], D=M4)
+                    self.dW(dqkv, xm.d, gw[:3 * D]); self.dW(du, xm.d, gw[3 * D:])
+                if adapted:
+                    dx = bw1(dqkv)
+                else:
+                    dx = self.E(M, D)
+                    ops.gemm(dqkv, self._wt_rows(pre + "linear1.weight", 0, 3 * D), dx, None)
                 dx2 = self.E(M, D)
                 ops.gemm(du, self._wt_rows(pre + "linear1.weight", 3 * D, 3 * D + M4), dx2, None, epilogue=EPI_GATED_RES, residual=dx)
                 self.acc(xm, dx2)
@@ -315,7 +546,7 @@ class _HYRun(_STRun):
                 self.acc(x, g_)
                 ops.group_colsum(g_, None, y=branch, out2=dsl(2), D=D, S=Lj, St=0, grouped=True, o_bstride=bs, o_segstride=0)
                 gg = self.E(M, D); ops.gate_mul(g_, gg, sl(2), sl(2), bs, D, Lj, 0)
-                ops.group_colsum(gg, self.G(pre + "linear2.bias"), D=D)
+                self.colsum(gg, pre + "linear2.bias", D)
                 self.dW(gg, cat, self.G(pre + "linear2.weight"))
                 dcat = self.E(M, D + M4)
                 wt2 = self.P.wt[pre + "linear2.weight"]          # [D + M4, D]

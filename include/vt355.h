@@ -366,16 +366,18 @@ int vt_qk_rmsnorm_rope128_bwd(const void* dout, long long lddo, const void* qkv,
  * (modules/models.py:203-221, 362-378), and its autograd.  Element (b, s, head, d) of q / k / v / o / dout / dk / dv at
  * base + b*bs + s*rs + head*128 + d (bf16; the fused qkv projection is consumed in place); kv_len: int32 [B] on the device (valid rows
  * and keys of every sample, = cu_seqlens[2b+1] - cu_seqlens[2b]) or NULL; lse2: fp32 [B, H, S], log2-domain.
- * Backward: delta_ws fp32 [B*H*S] scratch; dq32 fp32 accumulator with row stride dq_rs / batch stride dq_bs, ZEROED BY THE CALLER
- * (softmax_scale-scaled sums are added atomically); dk, dv written for every row < S (zeros for keys >= kv_len[b]). */
+ * Backward: delta_ws fp32 [B*H*S] scratch.  dq_bf16 != NULL: two passes (dK / dV key-stationary; dQ query-stationary with S and dP recomputed),
+ * dQ written once in bf16 with row stride dqb_rs / batch stride dqb_bs (elements), dq32 untouched.  dq_bf16 == NULL: one pass, dQ added
+ * atomically (softmax_scale-scaled) to the fp32 accumulator dq32 (strides dq_rs / dq_bs), ZEROED BY THE CALLER.  dk, dv are written for every
+ * row < S (zeros for keys >= kv_len[b]). */
 int vt_attn128_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, const int* kv_len, int B, int H, int S,
                    long long q_rs, long long k_rs, long long v_rs, long long o_rs,
                    long long q_bs, long long k_bs, long long v_bs, long long o_bs, float softmax_scale, void* stream);
 int vt_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
-                   float* delta_ws, float* dq32, void* dk, void* dv, int B, int H, int S,
-                   long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dk_rs,
-                   long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs, long long dq_bs,
-                   long long dk_bs, long long dv_bs, float softmax_scale, void* stream);
+                   float* delta_ws, float* dq32, void* dq_bf16, void* dk, void* dv, int B, int H, int S,
+                   long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dqb_rs,
+                   long long dk_rs, long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
+                   long long dq_bs, long long dqb_bs, long long dk_bs, long long dv_bs, float softmax_scale, void* stream);
 
 #ifdef __cplusplus
 }

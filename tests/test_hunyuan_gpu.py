@@ -236,8 +236,12 @@ def test_attn128_matches_dense_attention(dev, B, S, H, lens):
     vm = valid[..., 0][:, None, :]
     assert ((lse.double().cpu() - lse_ref) * vm).abs().max().item() < 2e-2
     gr = x.grad
-    assert _rel(dq32, gr[:, :, :C]) < 2e-2
+    assert _rel(dq32, gr[:, :, :C]) < 2e-2                                                     # one pass: fp32 dQ accumulated atomically
     assert _rel(dqkv[:, :, C:2 * C], gr[:, :, C:2 * C]) < 2e-2 and _rel(dqkv[:, :, 2 * C:], gr[:, :, 2 * C:]) < 2e-2
+    d2 = torch.full((B, S, 3 * C), 7.0, dtype=BF, device=dev)                                  # two passes: bf16 dQ written once, in place
+    ops.attn128_bwd(q, k, v, o, g.to(dev), lse, d2[:, :, :C], d2[:, :, C:2 * C], d2[:, :, 2 * C:], H, scale, kv_len=kvd)
+    assert _rel(d2[:, :, :C].double().cpu() * valid, gr[:, :, :C] * valid) < 2e-2
+    assert torch.equal(d2[:, :, C:], dqkv[:, :, C:])                                           # the dK / dV pass is the same arithmetic
     if kv is not None:
         for b in range(B):
             assert dqkv[b, lens[b]:, C:].abs().max().item() == 0 if lens[b] < S else True
@@ -264,9 +268,9 @@ def test_attn128_full_length_properties(dev):
     assert (o.float().abs() <= vmax * 1.01 + 1e-3).all() and torch.isfinite(lse[:, :, :S - 56]).all()
 
     def bwd(g):
-        dq = torch.empty(B, S, C, device=dev); d = torch.empty(B, S, 2 * C, dtype=BF, device=dev)
-        ops.attn128_bwd(q, k, v, o, g, lse, dq, d[:, :, :C], d[:, :, C:], H, scale, kv_len=kv)
-        return dq, d[:, :, :C].float(), d[:, :, C:].float()
+        d = torch.empty(B, S, 3 * C, dtype=BF, device=dev)
+        ops.attn128_bwd(q, k, v, o, g, lse, d[:, :, :C], d[:, :, C:2 * C], d[:, :, 2 * C:], H, scale, kv_len=kv)      # two-pass backward
+        return d[:, :, :C].float(), d[:, :, C:2 * C].float(), d[:, :, 2 * C:].float()
     g1 = torch.randn(B, S, C, device=dev, generator=gen).to(BF); g2 = torch.randn(B, S, C, device=dev, generator=gen).to(BF)
     g1[:, S - 56:] = 0; g2[:, S - 56:] = 0
     dq1, dk1, dv1 = bwd(g1)

@@ -29,4 +29,7 @@ print(f"attn_gen hd128 S={S} H={H}: fwd {f:.2f} ms = {fl / f / 1e9:.0f} TF/s; bw
 dq32 = torch.empty(B, S, C, device=dev); dkb = torch.empty(B, S, C, dtype=BF, device=dev); dvb = torch.empty(B, S, C, dtype=BF, device=dev)
 f2 = t(lambda: ops.attn128_fwd(q, k, v, o, lse, H, hd ** -0.5, kv_len=kv_len))
 g2 = t(lambda: ops.attn128_bwd(q, k, v, o, do, lse, dq32, dkb, dvb, H, hd ** -0.5, kv_len=kv_len))
-print(f"attn128  hd128 S={S} H={H}: fwd {f2:.2f} ms = {fl / f2 / 1e9:.0f} TF/s; bwd {g2:.2f} ms = {2 * fl / g2 / 1e9:.0f} TF/s algorithmic (incl. delta pre-pass and dQ memset)")
+print(f"attn128  hd128 S={S} H={H}: fwd {f2:.2f} ms = {fl / f2 / 1e9:.0f} TF/s; one-pass bwd (fp32 dQ atomics) {g2:.2f} ms = {2 * fl / g2 / 1e9:.0f} TF/s algorithmic (incl. delta pre-pass and dQ memset)")
+dqb = torch.empty(B, S, C, dtype=BF, device=dev)
+g3 = t(lambda: ops.attn128_bwd(q, k, v, o, do, lse, dqb, dkb, dvb, H, hd ** -0.5, kv_len=kv_len))
+print(f"attn128  hd128 S={S} H={H}: two-pass bwd (dK/dV pass + dQ pass) {g3:.2f} ms = {2 * fl / g3 / 1e9:.0f} TF/s algorithmic (incl. delta pre-pass)")

@@ -83,7 +83,7 @@ PROTOTYPES = {
     "vt_qk_rmsnorm_rope128_fwd": [_vp, _ll, _vp, _ll, _vp, _vp, _fp, _fp, _fp, _ll, _i, _i, _i, _i, _i, _f, _vp],
     "vt_qk_rmsnorm_rope128_bwd": [_vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _ll, _i, _i, _i, _i, _i, _vp],
     "vt_attn128_fwd": [_vp, _vp, _vp, _vp, _fp, _vp, _i, _i, _i] + [_ll] * 8 + [_f, _vp],
-    "vt_attn128_bwd": [_vp, _vp, _vp, _vp, _vp, _fp, _vp, _fp, _fp, _vp, _vp, _i, _i, _i] + [_ll] * 16 + [_f, _vp],
+    "vt_attn128_bwd": [_vp, _vp, _vp, _vp, _vp, _fp, _vp, _fp, _fp, _vp, _vp, _vp, _i, _i, _i] + [_ll] * 18 + [_f, _vp],
     "vt_gemm_fp8": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _fp, _fp, _vp],
     "vt_quantize_fp8": [_vp, _ll, _vp, _ll, _ll, _i, _fp, _vp, _i, _vp],
     "vt_opensora_loss": [_fp, _fp, _fp, _vp, _vp, _fp, _ll, _i, _i, _f, _vp],

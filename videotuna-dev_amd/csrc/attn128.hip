@@ -11,6 +11,7 @@
 struct Attn128Params {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
     const bf16_t* dout; const float* delta; float* dq32; bf16_t* dk; bf16_t* dv;
+    bf16_t* dqb; long long dqb_rs, dqb_bs;       // two-pass backward: dQ written directly (bf16)
     float* lse2;             // [B, H, S] log2-domain logsumexp of score * scale * log2(e)
     const int* kv_len;       // [B] valid keys (and rows) per sample, or null
     int S, H, B;
@@ -232,6 +233,7 @@ extern "C" int vt_attn128_fwd(const void* q, const void* k, const void* v, void*
 __device__ __forceinline__ int b128_swz_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 __device__ __forceinline__ int b128_swz_off(int row, int chunk) { return row * 128 + ((chunk ^ b128_swz_f(row)) << 4); }
 
+template <bool DQ>        // DQ = false: the dK / dV pass of the two-pass backward (no dS image, no K image, no dQ phase, no atomics)
 __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
     __shared__ __attribute__((aligned(16))) char smem[B128_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
     const float* dl_b = p.delta + (size_t)bh * p.S;
 
     // ---- K block image (B operand of dQ), both planes: 128 keys x 16 chunks, 8 per thread ----
+    if constexpr (DQ)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = tid + 256 * j;
@@ -411,16 +414,19 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                         dk_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(qimg + trA[dt][0], qimg + trA[dt][1]), dsb, dk_acc[pl][dt], 0, 0, 0);
                     }
             }
-            char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
+            if constexpr (DQ) {
+                char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
-                *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+                for (int gg = 0; gg < 4; ++gg) {
+                    const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
+                    *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+                }
             }
         }
-        stage_finish(t + 1, t == 0);
+        stage_finish(t + 1, DQ ? t == 0 : true);
         __syncthreads();
         stage(t + 2);
+        if constexpr (DQ) {
         // ---- dQ: one 32 x 32 tile per plane and wave over all 128 keys ----
         const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
 #pragma unroll
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dq_acc[i] * p.scale, rdq, dq_voff + pl * 256, soff + ((i & 3) + 8 * (i >> 2)) * dq_rowb, 0);
 #endif
         }
+        }       // if constexpr (DQ)
     }
     // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----
     {
@@ -466,6 +473,145 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                         *(u32x2*)(dvp + 64 * pl + 32 * dt + 8 * gg + 4 * h) = c;
                     }
         }
+    }
+}
+
+// ---- dQ pass of the two-pass backward: query-stationary, the forward kernel's structure.  One workgroup = 4 waves = 128 query rows; Q and dO
+// fragments live in registers, K / V tiles of 64 keys x 2 planes come through LDS (DMA, double buffered).  Per 32-key sub-tile:
+// S^T = K Q^T and dP^T = V dO^T (lane = query, so -lse2 and -delta are lane-local), dS^T = exp2(c S^T - lse2) (dP^T - delta) packed to bf16
+// is directly the B operand of dQ^T += K^T dS^T (A = transposed reads of the K tile).  Recomputing S and dP costs two products more than the
+// one-pass backward (7 instead of 5), and buys a dQ that is written once, in bf16, instead of S/128 fp32 atomic adds per element: at
+// HunyuanVideo's lengths the atomics were 6 of the backward's 9.5 ms.
+__global__ __launch_bounds__(256, 2) void attn128_dq_kernel(Attn128Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];     // 2 buffers x (K plane0 | K plane1 | V plane0 | V plane1) x 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5, g = lane >> 4, ql = (lane & 15) >> 2, pl4 = lane & 3;
+    const int nqt = (p.S + 127) / 128;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = id % nqt, bh = id / nqt;
+    const int head = bh % p.H, b = bh / p.H;
+    const int klen = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int q0 = qt * 128 + wave * 32;
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 128;
+    const bf16_t* kb = p.k + (size_t)b * p.k_bs + head * 128;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 128;
+    const bf16_t* dob = p.dout + (size_t)b * p.do_bs + head * 128;
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 256));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 256));
+    int qrow = q0 + r;
+    if (qrow > p.S - 1) qrow = p.S - 1;
+    bf16x8 qf[2][4], dof[2][4];
+    {
+        const bf16_t* qp = qb + (size_t)qrow * p.q_rs + 8 * h;
+        const bf16_t* dp = dob + (size_t)qrow * p.do_rs + 8 * h;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { qf[pl][s] = *(const bf16x8*)(qp + 64 * pl + 16 * s); dof[pl][s] = *(const bf16x8*)(dp + 64 * pl + 16 * s); }
+    }
+    const float lse_q = p.lse2[(size_t)bh * p.S + qrow], dl_q = p.delta[(size_t)bh * p.S + qrow];
+    int kd_voff[2], vd_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 8 * (wave + 4 * j) + (lane >> 3);
+        const int c = ((lane & 7) ^ b128_swz_f(key)) << 4;          // ONE swizzle for both images: row reads and transposed reads conflict-free
+        kd_voff[j] = (int)(key * p.k_rs * 2) + c;
+        vd_voff[j] = (int)(key * p.v_rs * 2) + c;
+    }
+    auto dma = [&](int t, int buf) {
+        const int ks = (int)((long long)t * 64 * p.k_rs * 2), vs = (int)((long long)t * 64 * p.v_rs * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                char* dst = smem + buf * 32768 + pl * 8192 + (wave + 4 * j) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kd_voff[j] + pl * 128, ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + 16384), 16, vd_voff[j] + pl * 128, vs, 0, 0);
+            }
+    };
+    int rowrd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rowrd[s] = r * 128 + (((2 * s + h) ^ b128_swz_f(r)) << 4);
+    int trA[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec) {
+            const int fx = ((ql >> 1) << 2) | (sec << 1) | h;
+            trA[dt][sec] = (4 * h + ql + 8 * sec) * 128 + (((4 * dt + 2 * (g & 1) + (pl4 >> 1)) ^ fx) << 4) + (pl4 & 1) * 8;
+        }
+    f32x16 dq_acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq_acc[a][c][i] = 0.f;
+    const float sc = p.scale_log2;
+    const int nt = (klen + 63) / 64;
+    if (nt > 0) dma(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma(t + 1, buf ^ 1);
+        const char* base = smem + buf * 32768;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 ka = *(const bf16x8*)(base + pl * 8192 + kt2 * 4096 + rowrd[s]);
+                    const bf16x8 va = *(const bf16x8*)(base + 16384 + pl * 8192 + kt2 * 4096 + rowrd[s]);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[pl][s], sacc, 0, 0, 0);       // S^T  [key rows][query lane]
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[pl][s], pacc, 0, 0, 0);      // dP^T
+                }
+            const bool ragged = (t * 64 + kt2 * 32 + 32) > klen;
+            unsigned dw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[2 * i], sc, -lse_q));
+                float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[2 * i + 1], sc, -lse_q));
+                if (ragged) {
+                    const int key = t * 64 + kt2 * 32 + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * h;
+                    if (key >= klen) p0 = 0.f;
+                    if (key + 1 >= klen) p1 = 0.f;
+                }
+                dw[i] = pack2(p0 * (pacc[2 * i] - dl_q), p1 * (pacc[2 * i + 1] - dl_q));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+                const bf16x8 dsb = __builtin_bit_cast(bf16x8, db4);
+                const int ro = (32 * kt2 + 16 * s2) * 128;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* kimg = base + pl * 8192 + ro;
+                        dq_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(kimg + trA[dt][0], kimg + trA[dt][1]), dsb, dq_acc[pl][dt], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (q0 + r < p.S) {
+        bf16_t* op = p.dqb + (size_t)b * p.dqb_bs + (size_t)(q0 + r) * p.dqb_rs + head * 128;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u32x2 wv;
+                    wv[0] = pack2(dq_acc[pl][dt][4 * g4 + 0] * p.scale, dq_acc[pl][dt][4 * g4 + 1] * p.scale);
+                    wv[1] = pack2(dq_acc[pl][dt][4 * g4 + 2] * p.scale, dq_acc[pl][dt][4 * g4 + 3] * p.scale);
+                    *(u32x2*)(op + 64 * pl + 32 * dt + 8 * g4 + 4 * h) = wv;
+                }
     }
 }
 
@@ -492,23 +638,27 @@ __global__ __launch_bounds__(256) void attn128_delta_kernel(const bf16_t* o, con
     if (row < total && sub == 0) delta[((size_t)(bs / S) * H + hh) * S + (bs % S)] = acc;
 }
 
-// dq32: fp32 accumulator (element (b, s, head, d) at b*dq_bs + s*dq_rs + head*128 + d), ZEROED BY THE CALLER, scaled sums are added to it;
+// Two ways to the same gradients.  dq_bf16 != NULL (what the host layer uses): TWO PASSES -- dK / dV key-stationary, dQ query-stationary with S
+// and dP recomputed; dQ is written once, in bf16 (element (b, s, head, d) at dq_bf16 + b*dqb_bs + s*dqb_rs + head*128 + d); dq32 is not touched.
+// dq_bf16 == NULL: ONE PASS, dQ added atomically to the fp32 accumulator dq32 (element at b*dq_bs + s*dq_rs + head*128 + d, ZEROED BY THE CALLER).
 // dk, dv bf16 like k, v (every row < S is written; keys >= kv_len[b] get zeros).  delta_ws: fp32 [B*H*S] scratch.
 extern "C" int vt_attn128_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse2, const int* kv_len,
-                              float* delta_ws, float* dq32, void* dk, void* dv, int B, int H, int S,
-                              long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dk_rs,
-                              long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs, long long dq_bs,
-                              long long dk_bs, long long dv_bs, float softmax_scale, void* stream) {
+                              float* delta_ws, float* dq32, void* dq_bf16, void* dk, void* dv, int B, int H, int S,
+                              long long q_rs, long long k_rs, long long v_rs, long long o_rs, long long do_rs, long long dq_rs, long long dqb_rs,
+                              long long dk_rs, long long dv_rs, long long q_bs, long long k_bs, long long v_bs, long long o_bs, long long do_bs,
+                              long long dq_bs, long long dqb_bs, long long dk_bs, long long dv_bs, float softmax_scale, void* stream) {
     int rc = a128_check(B, H, S, q_rs, k_rs, v_rs, dk_rs);
     if (rc != VT_OK) return rc;
     if ((o_rs % 8) || (do_rs % 8) || (dv_rs % 4) || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 8) || (do_bs % 8) || (dk_bs % 4) || (dv_bs % 4))
         return VT_ERR_BAD_SHAPE;
-    if (lse2 == nullptr || delta_ws == nullptr || dq32 == nullptr || dq_rs < (long long)H * 128) return VT_ERR_BAD_SHAPE;
+    if (lse2 == nullptr || delta_ws == nullptr || (dq32 == nullptr && dq_bf16 == nullptr)) return VT_ERR_BAD_SHAPE;
+    if (dq_bf16 == nullptr && dq_rs < (long long)H * 128) return VT_ERR_BAD_SHAPE;
+    if (dq_bf16 != nullptr && ((dqb_rs % 4) || (dqb_bs % 4) || dqb_rs < (long long)H * 128 || (((uintptr_t)dq_bf16) & 7))) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o) | ((uintptr_t)dout)) & 15) return VT_ERR_BAD_ALIGN;
     if ((((uintptr_t)dk) | ((uintptr_t)dv)) & 7) return VT_ERR_BAD_ALIGN;
     const long long lim = 0x7fffff00LL;
     if ((long long)S * q_rs * 2 >= lim || (long long)S * k_rs * 2 >= lim || (long long)S * v_rs * 2 >= lim || (long long)S * do_rs * 2 >= lim ||
-        (long long)S * dq_rs * 4 >= lim) return VT_ERR_BAD_SHAPE;
+        (dq_bf16 == nullptr && (long long)S * dq_rs * 4 >= lim)) return VT_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     {
         const long long total = (long long)B * S * H * 16;
@@ -518,11 +668,17 @@ extern "C" int vt_attn128_bwd(const void* q, const void* k, const void* v, const
     Attn128Params p = {};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout; p.lse2 = const_cast<float*>(lse2);
     p.delta = delta_ws; p.dq32 = dq32; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.kv_len = kv_len;
+    p.dqb = (bf16_t*)dq_bf16; p.dqb_rs = dqb_rs; p.dqb_bs = dqb_bs;
     p.S = S; p.H = H; p.B = B;
     p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.do_rs = do_rs; p.dq_rs = dq_rs; p.dk_rs = dk_rs; p.dv_rs = dv_rs;
     p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.do_bs = do_bs; p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs;
     p.scale = softmax_scale; p.scale_log2 = softmax_scale * 1.4426950408889634f;
     const int nkb = (S + 127) / 128;
-    hipLaunchKernelGGL(attn128_bwd_kernel, dim3((unsigned)(nkb * H * B)), dim3(256), 0, st, p);
+    if (dq_bf16 != nullptr) {
+        hipLaunchKernelGGL(attn128_bwd_kernel<false>, dim3((unsigned)(nkb * H * B)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn128_dq_kernel, dim3((unsigned)(nkb * H * B)), dim3(256), 0, st, p);       // (S + 127) / 128 query tiles as well
+    } else {
+        hipLaunchKernelGGL(attn128_bwd_kernel<true>, dim3((unsigned)(nkb * H * B)), dim3(256), 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

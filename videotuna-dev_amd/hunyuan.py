@@ -438,10 +438,8 @@ class _HYRun(_STRun):
                 g3 = g.view(B, Lj, g.shape[1]) if g.is_contiguous() else g.as_strided((B, Lj, C), (Lj * g.stride(0), g.stride(0), 1))
                 dj = self.E(B * Lj, 3 * C)
                 d3 = dj.view(B, Lj, 3 * C)
-                dq32 = self.E(B, Lj, C, dt=F32)
-                ops.attn128_bwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], g3[:, :, :C], lse, dq32, d3[:, :, C:2 * C],
-                                d3[:, :, 2 * C:], H, scale, kv_len=kv_len)
-                ops.residual_cast(dq32.view(B * Lj, C), None, dj[:, :C])
+                ops.attn128_bwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], g3[:, :, :C], lse, d3[:, :, :C], d3[:, :, C:2 * C],
+                                d3[:, :, 2 * C:], H, scale, kv_len=kv_len)        # two-pass backward: dQ, dK, dV straight into the joint gradient
                 djoint_ref[0] = dj
             self.tape.append(bwd_joint_attention)
         return ov

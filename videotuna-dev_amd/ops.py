@@ -852,17 +852,21 @@ def attn128_fwd(q, k, v, o, lse2, H: int, scale: float, kv_len=None):
                                         scale, _stream()), "vt_attn128_fwd")
 
 
-def attn128_bwd(q, k, v, o, do, lse2, dq32, dk, dv, H: int, scale: float, kv_len=None):
-    """dq32: fp32 [B, S, H*128] accumulator, zeroed here; dk, dv bf16 views like k, v"""
+def attn128_bwd(q, k, v, o, do, lse2, dq, dk, dv, H: int, scale: float, kv_len=None):
+    """dq: bf16 view like q -> two-pass backward (dQ written once); fp32 [B, S, H*128] -> one-pass backward, dQ accumulated atomically (zeroed
+    here); dk, dv bf16 views like k, v"""
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o), ("do", do), ("dk", dk), ("dv", dv)):
         _req(t, BF16, n, 3)
-    _req(dq32, torch.float32, "dq32", 3)
     B, S = q.shape[0], q.shape[1]
     delta = torch.empty(B * H * S, dtype=torch.float32, device=q.device)
-    dq32.zero_()
+    two_pass = dq.dtype == BF16
+    if not two_pass:
+        _req(dq, torch.float32, "dq", 3)
+        dq.zero_()
     with _timed("attn128_bwd", 8.0 * S * S * H * 128 * B):
         check(load_library().vt_attn128_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse2.data_ptr(), _p(kv_len),
-                                            delta.data_ptr(), dq32.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S,
-                                            q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1), dq32.stride(1), dk.stride(1), dv.stride(1),
-                                            q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq32.stride(0), dk.stride(0), dv.stride(0),
+                                            delta.data_ptr(), None if two_pass else dq.data_ptr(), dq.data_ptr() if two_pass else None,
+                                            dk.data_ptr(), dv.data_ptr(), B, H, S,
+                                            q.stride(1), k.stride(1), v.stride(1), o.stride(1), do.stride(1), dq.stride(1), dq.stride(1), dk.stride(1), dv.stride(1),
+                                            q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
                                             scale, _stream()), "vt_attn128_bwd")

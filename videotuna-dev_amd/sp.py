@@ -154,11 +154,10 @@ class _DeviceCore(torch.autograd.Function):
         from . import ops
         q3, k3, v3, o, lse = ctx.saved_tensors
         B, S, C = q3.shape
-        dq32 = torch.empty(B, S, C, dtype=torch.float32, device=q3.device)
-        dk = torch.empty_like(q3); dv = torch.empty_like(q3)
-        ops.attn128_bwd(q3, k3, v3, o, g.contiguous().view(B, S, C), lse, dq32, dk, dv, ctx.h, 128 ** -0.5, kv_len=ctx.kv_len)
+        dq = torch.empty_like(q3); dk = torch.empty_like(q3); dv = torch.empty_like(q3)
+        ops.attn128_bwd(q3, k3, v3, o, g.contiguous().view(B, S, C), lse, dq, dk, dv, ctx.h, 128 ** -0.5, kv_len=ctx.kv_len)
         sh = (B, S, ctx.h, 128)
-        return dq32.to(q3.dtype).view(sh), dk.view(sh), dv.view(sh), None
+        return dq.view(sh), dk.view(sh), dv.view(sh), None
 
 
 def device_core(q, k, v, kv_len):

@@ -138,3 +138,130 @@ def flow_matching(x0, noise, sigma):
     """hunyuanvideo.py:931-966: noisy latents and the regression target of the flow-matching loss"""
     s = sigma.view(-1, *([1] * (x0.dim() - 1)))
     return (1.0 - s) * x0 + s * noise, noise - x0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The rest of HYVideoDiffusionTransformer (models.py:396-720): embedders, token refiner, final layer, unpatchify.  Pinned by
+# tests/golden/hunyuan_model.npz (the reference's own class imported at a tiny size: tests/golden/make_golden_hunyuan.py).
+#   PatchEmbed (Conv3d kernel = stride = patch) ......... modules/embed_layers.py:9-55
+#   TimestepEmbedder / timestep_embedding ............... modules/embed_layers.py:86-157 (cos | sin, max_period 1e4, Linear-SiLU-Linear)
+#   TextProjection, MLPEmbedder ......................... modules/embed_layers.py:58-84, modules/mlp_layers.py:63-75
+#   SingleTokenRefiner / IndividualTokenRefiner[Block] .. modules/token_refiner.py:16-236 (LayerNorm affine, self-attention over the text
+#       tokens with mask (valid x valid) | key 0, gates from SiLU-Linear(c), MLP with SiLU)
+#   FinalLayer .......................................... modules/mlp_layers.py:78-118
+def model_shapes(D, H, n_double, n_single, in_ch, out_ch, patch, text_dim, text_dim_2, ratio=4.0, refiner_depth=2, guidance=False):
+    M4 = int(D * ratio)
+    pt, ph, pw = patch
+    sh = {"img_in.proj.weight": (D, in_ch, pt, ph, pw), "img_in.proj.bias": (D,),
+          "txt_in.input_embedder.weight": (D, text_dim), "txt_in.input_embedder.bias": (D,),
+          "txt_in.t_embedder.mlp.0.weight": (D, 256), "txt_in.t_embedder.mlp.0.bias": (D,),
+          "txt_in.t_embedder.mlp.2.weight": (D, D), "txt_in.t_embedder.mlp.2.bias": (D,),
+          "txt_in.c_embedder.linear_1.weight": (D, text_dim), "txt_in.c_embedder.linear_1.bias": (D,),
+          "txt_in.c_embedder.linear_2.weight": (D, D), "txt_in.c_embedder.linear_2.bias": (D,)}
+    for i in range(refiner_depth):
+        p = f"txt_in.individual_token_refiner.blocks.{i}."
+        sh.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "self_attn_qkv.weight": (3 * D, D), p + "self_attn_qkv.bias": (3 * D,),
+                   p + "self_attn_proj.weight": (D, D), p + "self_attn_proj.bias": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                   p + "mlp.fc1.weight": (M4, D), p + "mlp.fc1.bias": (M4,), p + "mlp.fc2.weight": (D, M4), p + "mlp.fc2.bias": (D,),
+                   p + "adaLN_modulation.1.weight": (2 * D, D), p + "adaLN_modulation.1.bias": (2 * D,)})
+    sh.update({"time_in.mlp.0.weight": (D, 256), "time_in.mlp.0.bias": (D,), "time_in.mlp.2.weight": (D, D), "time_in.mlp.2.bias": (D,),
+               "vector_in.in_layer.weight": (D, text_dim_2), "vector_in.in_layer.bias": (D,),
+               "vector_in.out_layer.weight": (D, D), "vector_in.out_layer.bias": (D,)})
+    if guidance:
+        sh.update({"guidance_in.mlp.0.weight": (D, 256), "guidance_in.mlp.0.bias": (D,), "guidance_in.mlp.2.weight": (D, D), "guidance_in.mlp.2.bias": (D,)})
+    for i in range(n_double):
+        sh.update(double_block_shapes(D, H, ratio, f"double_blocks.{i}."))
+    for i in range(n_single):
+        sh.update(single_block_shapes(D, H, ratio, f"single_blocks.{i}."))
+    sh.update({"final_layer.linear.weight": (pt * ph * pw * out_ch, D), "final_layer.linear.bias": (pt * ph * pw * out_ch,),
+               "final_layer.adaLN_modulation.1.weight": (2 * D, D), "final_layer.adaLN_modulation.1.bias": (2 * D,)})
+    return sh
+
+
+def init_model(shapes: Dict[str, tuple], seed: int):
+    """like init(), conv weights with their own fan-in, every bias / norm non-trivial (the reference zero-initialises several: a test that
+    multiplies by zero pins nothing)"""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, s in shapes.items():
+        if len(s) == 1:
+            out[k] = torch.randn(s, generator=g) * 0.05 + (1.0 if k.endswith("norm.weight") or ".norm1.weight" in k or ".norm2.weight" in k else 0.0)
+        else:
+            fan = 1
+            for d in s[1:]:
+                fan *= d
+            out[k] = torch.randn(s, generator=g) * (0.7 / fan ** 0.5)
+    return out
+
+
+def timestep_embedding(t, dim=256, max_period=10000):
+    import math
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _tembed(t, P, pre, dtype):
+    e = timestep_embedding(t).to(dtype)
+    return F.linear(F.silu(F.linear(e, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"])), P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"])
+
+
+def token_refiner(text_states, t, mask, P, H, depth=2):
+    """SingleTokenRefiner.forward (token_refiner.py:199-236) with IndividualTokenRefiner's mask (:136-160)"""
+    pre = "txt_in."
+    B, L, _ = text_states.shape
+    temb = _tembed(t, P, pre + "t_embedder.", text_states.dtype)
+    if mask is None:
+        ctx = text_states.mean(1)
+    else:
+        mf = mask.to(text_states.dtype).unsqueeze(-1)
+        ctx = (text_states * mf).sum(1) / mf.sum(1)
+    ctx = F.linear(F.silu(F.linear(ctx, P[pre + "c_embedder.linear_1.weight"], P[pre + "c_embedder.linear_1.bias"])),
+                   P[pre + "c_embedder.linear_2.weight"], P[pre + "c_embedder.linear_2.bias"])
+    c = temb + ctx
+    x = F.linear(text_states, P[pre + "input_embedder.weight"], P[pre + "input_embedder.bias"])
+    D = x.shape[-1]
+    am = None
+    if mask is not None:
+        m1 = mask.bool().view(B, 1, 1, L).repeat(1, 1, L, 1)
+        am = m1 & m1.transpose(2, 3)
+        am[:, :, :, 0] = True
+    for i in range(depth):
+        p = f"{pre}individual_token_refiner.blocks.{i}."
+        g_msa, g_mlp = F.linear(F.silu(c), P[p + "adaLN_modulation.1.weight"], P[p + "adaLN_modulation.1.bias"]).chunk(2, dim=1)
+        nx = F.layer_norm(x, (D,), P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-6)
+        qkv = F.linear(nx, P[p + "self_attn_qkv.weight"], P[p + "self_attn_qkv.bias"]).view(B, L, 3, H, D // H)
+        q, k, v = (qkv[:, :, j].transpose(1, 2) for j in range(3))
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(B, L, D)
+        x = x + F.linear(a, P[p + "self_attn_proj.weight"], P[p + "self_attn_proj.bias"]) * g_msa[:, None]
+        h = F.layer_norm(x, (D,), P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-6)
+        h = F.linear(F.silu(F.linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])), P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"])
+        x = x + h * g_mlp[:, None]
+    return x
+
+
+def transformer_forward(P, x, t, text_states, text_mask, text_states_2, cos, sin, H, n_double, n_single, patch, out_ch, guidance=None):
+    """HYVideoDiffusionTransformer.forward (models.py:592-700).  x [B, C, T, Hh, Ww]; text_mask [B, L] int (1 = valid)"""
+    B, C, T, Hh, Ww = x.shape
+    pt, ph, pw = patch
+    tt, th, tw = T // pt, Hh // ph, Ww // pw
+    vec = _tembed(t, P, "time_in.", x.dtype)
+    vec = vec + F.linear(F.silu(F.linear(text_states_2, P["vector_in.in_layer.weight"], P["vector_in.in_layer.bias"])),
+                         P["vector_in.out_layer.weight"], P["vector_in.out_layer.bias"])
+    if guidance is not None:
+        vec = vec + _tembed(guidance, P, "guidance_in.", x.dtype)
+    img = F.conv3d(x, P["img_in.proj.weight"], P["img_in.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    txt = token_refiner(text_states, t, text_mask, P, H)
+    Lt = txt.shape[1]
+    tv = text_mask.sum(1)
+    for i in range(n_double):
+        img, txt = double_block(img, txt, vec, P, f"double_blocks.{i}.", H, tv, cos, sin)
+    xx = torch.cat([img, txt], 1)
+    for i in range(n_single):
+        xx = single_block(xx, vec, P, f"single_blocks.{i}.", H, Lt, tv, cos, sin)
+    img = xx[:, :img.shape[1]]
+    shift, scale = F.linear(F.silu(vec), P["final_layer.adaLN_modulation.1.weight"], P["final_layer.adaLN_modulation.1.bias"]).chunk(2, dim=1)
+    img = F.linear(_ln(img) * (1 + scale[:, None]) + shift[:, None], P["final_layer.linear.weight"], P["final_layer.linear.bias"])
+    img = img.reshape(B, tt, th, tw, out_ch, pt, ph, pw)
+    return torch.einsum("nthwcopq->nctohpwq", img).reshape(B, out_ch, tt * pt, th * ph, tw * pw)

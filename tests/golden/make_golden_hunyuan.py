@@ -91,6 +91,40 @@ def main():
     np.savez_compressed(os.path.join(HERE, "hunyuan_blocks.npz"), **rec)
     print("hunyuan_blocks:", len(rec), "arrays; double out", tuple(io.shape), "single out", tuple(xo.shape))
 
+    # ---- the whole HYVideoDiffusionTransformer at a tiny size (embedders, token refiner, 1 + 1 blocks, final layer, unpatchify) ----
+    from types import SimpleNamespace
+    def cu_cpu(text_mask, img_len):               # get_cu_seqlens (attenion.py:34-57) without its device="cuda"
+        Bq = text_mask.shape[0]
+        text_len = text_mask.sum(dim=1)
+        max_len = text_mask.shape[1] + img_len
+        c = torch.zeros([2 * Bq + 1], dtype=torch.int32)
+        for i in range(Bq):
+            c[2 * i + 1] = i * max_len + text_len[i] + img_len
+            c[2 * i + 2] = (i + 1) * max_len
+        return c
+    models.get_cu_seqlens = cu_cpu
+    Cin, T, Hh, Ww, Ltx, TD, TD2 = 4, 3, 8, 12, 12, 64, 32
+    net = models.HYVideoDiffusionTransformer(SimpleNamespace(text_states_dim=TD, text_states_dim_2=TD2), patch_size=[1, 2, 2], in_channels=Cin,
+                                             hidden_size=D, heads_num=H, mm_double_blocks_depth=1, mm_single_blocks_depth=1).eval()
+    shapes = HO.model_shapes(D, H, 1, 1, Cin, Cin, (1, 2, 2), TD, TD2)
+    assert {k: tuple(v.shape) for k, v in net.named_parameters()} == shapes, set(shapes) ^ {k for k, _ in net.named_parameters()}
+    Pm = HO.init_model(shapes, 3)
+    net.load_state_dict(Pm)
+    g2 = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Cin, T, Hh, Ww, generator=g2)
+    tstep = torch.tensor([37.0, 912.0])
+    ts_ = torch.randn(B, Ltx, TD, generator=g2); ts2 = torch.randn(B, TD2, generator=g2)
+    tmask = torch.zeros(B, Ltx, dtype=torch.int64); tmask[0, :5] = 1; tmask[1, :12] = 1
+    ntok = T * (Hh // 2) * (Ww // 2)
+    ang2 = torch.rand(ntok, D // H // 2, generator=g2) * 6.28
+    cos2, sin2 = torch.cos(ang2).repeat_interleave(2, dim=1), torch.sin(ang2).repeat_interleave(2, dim=1)
+    with torch.no_grad():
+        y = net(x, tstep, text_states=ts_, text_mask=tmask, text_states_2=ts2, freqs_cos=cos2, freqs_sin=sin2, return_dict=False)
+        txt_ref = net.txt_in(ts_, tstep, tmask)
+    np.savez_compressed(os.path.join(HERE, "hunyuan_model.npz"), x=x.numpy(), t=tstep.numpy(), text_states=ts_.numpy(), text_mask=tmask.numpy(),
+                        text_states_2=ts2.numpy(), cos=cos2.numpy(), sin=sin2.numpy(), out=y.numpy(), txt_refined=txt_ref.numpy())
+    print("hunyuan_model: out", tuple(y.shape), "refined text", tuple(txt_ref.shape))
+
 
 if __name__ == "__main__":
     main()

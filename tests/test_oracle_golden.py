@@ -420,3 +420,20 @@ def test_hunyuan_block_oracle_matches_reference_blocks():
     assert (x.grad - T("s_dx")).abs().max().item() < 2e-4 * T("s_dx").abs().max().item()
     assert (v2.grad - T("s_dvec")).abs().max().item() < 2e-4 * T("s_dvec").abs().max().item()
     check_grads(Ps, "s")
+
+
+def test_hunyuan_model_oracle_matches_reference_transformer():
+    """oracle/hunyuan_oracle.py::transformer_forward / token_refiner vs the reference's own HYVideoDiffusionTransformer (embedders, token refiner
+    with its mask, one double + one single block, final layer, unpatchify) imported at a tiny size by tests/golden/make_golden_hunyuan.py"""
+    import hunyuan_oracle as HO
+    g = np.load(os.path.join(G, "hunyuan_model.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    D, H = 256, 2
+    P = {k: v.double() for k, v in HO.init_model(HO.model_shapes(D, H, 1, 1, 4, 4, (1, 2, 2), 64, 32), 3).items()}
+    txt = HO.token_refiner(T("text_states").double(), T("t"), T("text_mask"), P, H)
+    valid = T("text_mask").bool()
+    assert (txt - T("txt_refined").double())[valid].abs().max().item() < 1e-5 * T("txt_refined").abs().max().item()
+    out = HO.transformer_forward(P, T("x").double(), T("t"), T("text_states").double(), T("text_mask"), T("text_states_2").double(),
+                                 T("cos").double(), T("sin").double(), H, 1, 1, (1, 2, 2), 4)
+    assert tuple(out.shape) == tuple(g["out"].shape)
+    assert (out - T("out").double()).abs().max().item() < 2e-5 * T("out").abs().max().item()

@@ -343,3 +343,89 @@ def test_lora_blocks_train_step_matches_oracle(dev):
     assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
     out2 = m(xi.detach(), xt.detach(), xv.detach(), tv.to(dev), (T("cos").to(dev), T("sin").to(dev)))     # repacked adapters are used
     assert (out2.float() - out.float()).abs().max().item() > 0
+
+
+def _model(dev, lora_rank=0):
+    import hunyuan_oracle as HO
+    from vt355.hunyuan import HYVideoDiffusionTransformer
+    m = HYVideoDiffusionTransformer(in_channels=4, hidden_size=256, heads_num=2, mm_double_blocks_depth=1, mm_single_blocks_depth=1,
+                                    text_states_dim=64, text_states_dim_2=32, lora_rank=lora_rank, lora_alpha=2.0)
+    P = HO.init_model(HO.model_shapes(256, 2, 1, 1, 4, 4, (1, 2, 2), 64, 32), 3)
+    m.load_state_dict(P, strict=False)
+    if lora_rank:
+        m.lora.init_weights(5, zero_b=False)
+    m.to(dev)
+    base = {k: v.detach().float().cpu().double() for k, v in m.named_parameters() if not k.startswith("lora.")}
+    return HO, m, base
+
+
+def test_whole_transformer_forward_matches_oracle_and_reference(dev):
+    """HYVideoDiffusionTransformer (patch embed, token refiner, modulation vector, 1 + 1 blocks, final layer, unpatchify) on the device vs the
+    fp64 oracle on the same bf16-rounded weights and vs the reference's own output (tests/golden/hunyuan_model.npz, fp32 weights)"""
+    HO, m, base = _model(dev)
+    g = np.load(os.path.join(G, "hunyuan_model.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        out = m(T("x").to(dev), T("t").to(dev), text_states=T("text_states").to(dev), text_mask=T("text_mask").to(dev),
+                text_states_2=T("text_states_2").to(dev), freqs_cos=T("cos").to(dev), freqs_sin=T("sin").to(dev), return_dict=False)
+        txt = m._refine_text(T("text_states").to(dev), T("t").to(dev), T("text_mask").to(dev))
+    rb = lambda k: T(k).to(BF).double()
+    ref = HO.transformer_forward(base, rb("x"), T("t"), rb("text_states"), T("text_mask"), rb("text_states_2"), T("cos").double(), T("sin").double(),
+                                 2, 1, 1, (1, 2, 2), 4)
+    tref = HO.token_refiner(rb("text_states"), T("t"), T("text_mask"), base, 2)
+    valid = T("text_mask").bool()
+    e_txt = _rel(txt.double().cpu()[valid], tref[valid])
+    e, e_gold = _rel(out, ref), _rel(out, T("out"))
+    print(f"[hunyuan model] refined text rel-L2 {e_txt:.3e}; output vs oracle {e:.3e}, vs reference golden {e_gold:.3e}")
+    assert tuple(out.shape) == tuple(g["out"].shape) and e_txt < 1e-2 and e < 1.5e-2 and e_gold < 2.5e-2
+
+
+def test_whole_transformer_lora_training_step(dev):
+    """the shipped recipe's shape of training: frozen denoiser + rank-4 adapters, flow-matching loss on the model output; adapter gradients vs
+    the oracle's autograd through the whole model on the effective weights"""
+    from vt355.hunyuan import flow_matching_loss
+    from vt355.optim import FusedAdamW
+    HO, m, base = _model(dev, lora_rank=4)
+    ts = m.enable_lora_training()
+    g = np.load(os.path.join(G, "hunyuan_model.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn(g["x"].shape, generator=gen); noise = torch.randn(g["x"].shape, generator=gen)
+    sigma = torch.tensor([0.3, 0.8])
+    xt, target = HO.flow_matching(x0, noise, sigma)
+    xt = xt.to(BF)
+    out = m(xt.to(dev), (sigma * 1000).to(dev), text_states=T("text_states").to(dev), text_mask=T("text_mask").to(dev),
+            text_states_2=T("text_states_2").to(dev), freqs_cos=T("cos").to(dev), freqs_sin=T("sin").to(dev), return_dict=False)
+    loss, dpred = flow_matching_loss(out.contiguous().view(2, -1), x0.view(2, -1).to(dev), noise.view(2, -1).to(dev))
+    out.backward(dpred.view(out.shape))
+    ad = {k[5:]: v.detach().float().cpu().double().requires_grad_(True) for k, v in m.named_parameters() if k.startswith("lora.")}
+    Pe = dict(base)
+    D, s = 256, m.lora.scaling
+    for mod, tags in m.lora.sites.items():
+        w = base[mod + ".weight"].clone()
+        for j, tg in enumerate(tags):
+            dot = "." + tg if tg else ""
+            w[j * D:(j + 1) * D] = w[j * D:(j + 1) * D] + s * ad[f"{mod}.lora_B{dot}.weight"] @ ad[f"{mod}.lora_A{dot}.weight"]
+        Pe[mod + ".weight"] = w
+    rb = lambda k: T(k).to(BF).double()
+    ref = HO.transformer_forward(Pe, xt.double(), sigma * 1000, rb("text_states"), T("text_mask"), rb("text_states_2"), T("cos").double(),
+                                 T("sin").double(), 2, 1, 1, (1, 2, 2), 4)
+    lref = ((ref - target.double()) ** 2).mean()
+    lref.backward()
+    print(f"[hunyuan model lora] loss dev {loss.item():.5f} oracle {lref.item():.5f}")
+    assert abs(loss.item() - lref.item()) < 2e-2 * lref.item()
+    worst = 0.0
+    for n in m.lora.shapes:
+        gd = m.lora._view(ts.grad, n).detach().double().cpu()
+        gr = ad[n].grad
+        e = (gd - gr).norm().item() / max(gr.norm().item(), 1e-12)
+        cos = torch.nn.functional.cosine_similarity(gd.flatten(), gr.flatten(), dim=0).item()
+        worst = max(worst, e)
+        assert cos > 0.97 and e < 0.25, (n, e, cos)
+    print(f"[hunyuan model lora] adapter grads worst rel-L2 {worst:.3e}")
+    opt = FusedAdamW(ts.params, lr=1e-3, fullft_state=ts)
+    before = ts.flat.clone()
+    opt.step()
+    assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
+    with pytest.raises(NotImplementedError):
+        m.enable_training()

@@ -103,7 +103,8 @@ class HunyuanBlocks(FlatParamModule):
     20 + 40 blocks in HunyuanVideo-T2V"""
 
     def __init__(self, hidden_size: int = 3072, heads_num: int = 24, mlp_width_ratio: float = 4.0, mm_double_blocks_depth: int = 20,
-                 mm_single_blocks_depth: int = 40, fp8: bool = False, lora_rank: int = 0, lora_alpha: float = 1.0):
+                 mm_single_blocks_depth: int = 40, fp8: bool = False, lora_rank: int = 0, lora_alpha: float = 1.0,
+                 shapes_before: Optional[Dict[str, tuple]] = None, shapes_after: Optional[Dict[str, tuple]] = None):
         super().__init__()
         if hidden_size // heads_num != 128 or hidden_size % 128:
             raise ValueError("HunyuanVideo heads are 128 wide")
@@ -114,7 +115,7 @@ class HunyuanBlocks(FlatParamModule):
             sh.update(_double_shapes(hidden_size, heads_num, mlp_width_ratio, f"double_blocks.{i}."))
         for i in range(mm_single_blocks_depth):
             sh.update(_single_shapes(hidden_size, heads_num, mlp_width_ratio, f"single_blocks.{i}."))
-        self._setup_flat(sh)
+        self._setup_flat({**(shapes_before or {}), **sh, **(shapes_after or {})})
         # LoRA mode: the block weights stay frozen (no fp32 master, no gradients, no dW GEMMs); only the adapters train
         self.lora = _HYLora(hidden_size, mm_double_blocks_depth, mm_single_blocks_depth, lora_rank, lora_alpha) if lora_rank > 0 else None
 
@@ -600,6 +601,194 @@ class _HYRun(_STRun):
         dvec = torch.empty(B, D, dtype=F32, device=self.dev)
         ops.silu_bwd(self._dsv, self._vec, dvec)
         return iv.g.view(B, Li, D), tv.g.view(B, Lt, D), dvec.to(BF16)
+
+
+class HYVideoDiffusionTransformer(HunyuanBlocks):
+    """The whole denoiser of hyvideo_t2v/modules/models.py:396-720 under the reference's constructor keys, parameter names and ``forward``
+    signature: PatchEmbed, SingleTokenRefiner, TimestepEmbedder / MLPEmbedder modulation vector, the block trunk (HunyuanBlocks), FinalLayer,
+    unpatchify.  What TRAINS: the rank-r adapters of ``lora_rank=r`` (the shipped recipe) -- embedders, token refiner and final layer are
+    frozen forward code (the final layer with its input gradient); full fine-tuning of the whole model is refused."""
+
+    def __init__(self, args=None, patch_size=(1, 2, 2), in_channels: int = 16, out_channels: Optional[int] = None, hidden_size: int = 3072,
+                 heads_num: int = 24, mlp_width_ratio: float = 4.0, mlp_act_type: str = "gelu_tanh", mm_double_blocks_depth: int = 20,
+                 mm_single_blocks_depth: int = 40, rope_dim_list=(16, 56, 56), qkv_bias: bool = True, qk_norm: bool = True, qk_norm_type: str = "rms",
+                 guidance_embed: bool = False, text_projection: str = "single_refiner", use_attention_mask: bool = True,
+                 text_states_dim: Optional[int] = None, text_states_dim_2: Optional[int] = None, fp8: bool = False, lora_rank: int = 0,
+                 lora_alpha: float = 1.0, dtype=None, device=None, **unused):
+        if text_projection != "single_refiner" or mlp_act_type != "gelu_tanh" or not qkv_bias or not qk_norm or qk_norm_type != "rms":
+            raise NotImplementedError("only the shipped HunyuanVideo-T2V configuration (single_refiner, gelu_tanh, rms qk-norm) is built")
+        if sum(rope_dim_list) != hidden_size // heads_num:
+            raise ValueError(f"Got {list(rope_dim_list)} but expected positional dim {hidden_size // heads_num}")
+        td = text_states_dim if text_states_dim is not None else getattr(args, "text_states_dim", 4096)
+        td2 = text_states_dim_2 if text_states_dim_2 is not None else getattr(args, "text_states_dim_2", 768)
+        D, M4 = hidden_size, int(hidden_size * mlp_width_ratio)
+        pt, ph, pw = patch_size
+        oc = in_channels if out_channels is None else out_channels
+        before = {"img_in.proj.weight": (D, in_channels, pt, ph, pw), "img_in.proj.bias": (D,),
+                  "txt_in.input_embedder.weight": (D, td), "txt_in.input_embedder.bias": (D,),
+                  "txt_in.t_embedder.mlp.0.weight": (D, 256), "txt_in.t_embedder.mlp.0.bias": (D,),
+                  "txt_in.t_embedder.mlp.2.weight": (D, D), "txt_in.t_embedder.mlp.2.bias": (D,),
+                  "txt_in.c_embedder.linear_1.weight": (D, td), "txt_in.c_embedder.linear_1.bias": (D,),
+                  "txt_in.c_embedder.linear_2.weight": (D, D), "txt_in.c_embedder.linear_2.bias": (D,)}
+        for i in range(2):
+            q = f"txt_in.individual_token_refiner.blocks.{i}."
+            before.update({q + "norm1.weight": (D,), q + "norm1.bias": (D,), q + "self_attn_qkv.weight": (3 * D, D), q + "self_attn_qkv.bias": (3 * D,),
+                           q + "self_attn_proj.weight": (D, D), q + "self_attn_proj.bias": (D,), q + "norm2.weight": (D,), q + "norm2.bias": (D,),
+                           q + "mlp.fc1.weight": (M4, D), q + "mlp.fc1.bias": (M4,), q + "mlp.fc2.weight": (D, M4), q + "mlp.fc2.bias": (D,),
+                           q + "adaLN_modulation.1.weight": (2 * D, D), q + "adaLN_modulation.1.bias": (2 * D,)})
+        before.update({"time_in.mlp.0.weight": (D, 256), "time_in.mlp.0.bias": (D,), "time_in.mlp.2.weight": (D, D), "time_in.mlp.2.bias": (D,),
+                       "vector_in.in_layer.weight": (D, td2), "vector_in.in_layer.bias": (D,),
+                       "vector_in.out_layer.weight": (D, D), "vector_in.out_layer.bias": (D,)})
+        if guidance_embed:
+            before.update({"guidance_in.mlp.0.weight": (D, 256), "guidance_in.mlp.0.bias": (D,),
+                           "guidance_in.mlp.2.weight": (D, D), "guidance_in.mlp.2.bias": (D,)})
+        after = {"final_layer.linear.weight": (pt * ph * pw * oc, D), "final_layer.linear.bias": (pt * ph * pw * oc,),
+                 "final_layer.adaLN_modulation.1.weight": (2 * D, D), "final_layer.adaLN_modulation.1.bias": (2 * D,)}
+        super().__init__(hidden_size, heads_num, mlp_width_ratio, mm_double_blocks_depth, mm_single_blocks_depth, fp8, lora_rank, lora_alpha,
+                         shapes_before=before, shapes_after=after)
+        self.patch_size, self.in_channels, self.out_channels, self.guidance_embed = tuple(patch_size), in_channels, oc, guidance_embed
+        self.text_states_dim, self.text_states_dim_2 = td, td2
+
+    def enable_training(self):
+        raise NotImplementedError("vt355 trains the HunyuanVideo denoiser through its LoRA adapters (lora_rank=r, enable_lora_training()); "
+                                  "embedders, token refiner and final layer are frozen forward code")
+
+    # ---- frozen pieces: plain kernel calls, no tape ----
+    def _w(self, name):
+        return self.flat(self.flat_bf16, name)
+
+    def _lin(self, x, wname, bname, out_dtype=BF16, **epi):
+        """x [M, K] bf16 -> x W^T + b; K padded to the GEMM's 64-wide K-tile where a (tiny) input dimension needs it"""
+        w, b = self._w(wname), self._w(bname)
+        K = w.shape[1]
+        if K % 64:
+            Kp = (K + 63) // 64 * 64
+            xp = torch.zeros(x.shape[0], Kp, dtype=BF16, device=x.device); xp[:, :K] = x
+            wp = torch.zeros(w.shape[0], Kp, dtype=BF16, device=x.device); wp[:, :K] = w
+            x, w = xp, wp
+        y = torch.empty(x.shape[0], w.shape[0], dtype=out_dtype, device=x.device)
+        ops.gemm(x.contiguous(), w, y, b, **epi)
+        return y
+
+    def _silu(self, x):
+        y = torch.empty_like(x)
+        ops.silu(x.contiguous(), y)
+        return y
+
+    def _tembed(self, t, pre):
+        """TimestepEmbedder (embed_layers.py:118-157): cos | sin table (a [B, 256] host-side formula), Linear - SiLU - Linear on the device"""
+        import math
+        half = 128
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        a = t.float()[:, None] * freqs[None]
+        e = torch.cat([torch.cos(a), torch.sin(a)], -1).to(BF16)
+        return self._lin(self._silu(self._lin(e, pre + "mlp.0.weight", pre + "mlp.0.bias")), pre + "mlp.2.weight", pre + "mlp.2.bias")
+
+    def _refine_text(self, text_states, t, mask):
+        """SingleTokenRefiner (token_refiner.py:163-236) on the device; padding rows attend the valid keys (the reference: key 0) -- they are
+        never read by a valid row downstream"""
+        B, L, _ = text_states.shape
+        D, H = self.hidden_size, self.heads_num
+        dev = text_states.device
+        temb = self._tembed(t, "txt_in.t_embedder.")
+        mf = mask.to(torch.float32).unsqueeze(-1)
+        ctx = ((text_states.float() * mf).sum(1) / mf.sum(1)).to(BF16)                 # masked mean over the tokens: [B, text_dim] (host-side reduction)
+        ctx = self._lin(self._silu(self._lin(ctx, "txt_in.c_embedder.linear_1.weight", "txt_in.c_embedder.linear_1.bias")),
+                        "txt_in.c_embedder.linear_2.weight", "txt_in.c_embedder.linear_2.bias")
+        c = torch.empty_like(temb); ops.add_rows(temb, ctx, c)
+        sc = self._silu(c)
+        x = self._lin(text_states.reshape(B * L, -1).to(BF16), "txt_in.input_embedder.weight", "txt_in.input_embedder.bias")
+        klen = mask.sum(1).to(torch.int32).contiguous()
+        for i in range(2):
+            q = f"txt_in.individual_token_refiner.blocks.{i}."
+            gates = self._lin(sc, q + "adaLN_modulation.1.weight", q + "adaLN_modulation.1.bias", out_dtype=F32)        # [B, 2 D]: msa | mlp
+            nx = torch.empty_like(x); mean = torch.empty(B * L, dtype=F32, device=dev); rstd = torch.empty_like(mean)
+            ops.ln_modulate_fwd(x, nx, self._w(q + "norm1.weight"), self._w(q + "norm1.bias"), None, mean, rstd, D, 1, 0, 1e-6)
+            qkv = self._lin(nx, q + "self_attn_qkv.weight", q + "self_attn_qkv.bias").view(B, L, 3 * D)
+            o = torch.empty(B, L, D, dtype=BF16, device=dev); lse = torch.empty(B, H, L, dtype=F32, device=dev)
+            ops.attn128_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], o, lse, H, 128 ** -0.5, kv_len=klen)
+            x = self._lin(o.view(B * L, D), q + "self_attn_proj.weight", q + "self_attn_proj.bias", epilogue=EPI_GATED_RES, residual=x,
+                          gate_txt=gates[:, :D], gate_vid=gates[:, :D], gate_bstride=2 * D, S=L, St=0)
+            ops.ln_modulate_fwd(x, nx, self._w(q + "norm2.weight"), self._w(q + "norm2.bias"), None, mean, rstd, D, 1, 0, 1e-6)
+            h = self._silu(self._lin(nx, q + "mlp.fc1.weight", q + "mlp.fc1.bias"))
+            x = self._lin(h, q + "mlp.fc2.weight", q + "mlp.fc2.bias", epilogue=EPI_GATED_RES, residual=x, gate_txt=gates[:, D:], gate_vid=gates[:, D:],
+                          gate_bstride=2 * D, S=L, St=0)
+        return x.view(B, L, D)
+
+    def forward(self, x, t, text_states=None, text_mask=None, text_states_2=None, freqs_cos=None, freqs_sin=None, guidance=None,
+                return_dict: bool = True):
+        """x [B, C, T, H, W], t [B] (0..1000), text_states [B, L, text_dim], text_mask [B, L] (1 = valid), text_states_2 [B, text_dim_2],
+        freqs_cos / freqs_sin fp32 [T' H' W', 128] -> [B, C_out, T, H, W] (models.py:592-700)"""
+        if not x.is_cuda:
+            raise RuntimeError("vt355 HYVideoDiffusionTransformer runs only on an MI355X device (no CPU fallback)")
+        B, C, T, Hh, Ww = x.shape
+        pt, ph, pw = self.patch_size
+        tt, th, tw = T // pt, Hh // ph, Ww // pw
+        N, D = tt * th * tw, self.hidden_size
+        with torch.no_grad():
+            vec = self._tembed(t, "time_in.")
+            v2 = self._lin(self._silu(self._lin(text_states_2.to(BF16), "vector_in.in_layer.weight", "vector_in.in_layer.bias")),
+                           "vector_in.out_layer.weight", "vector_in.out_layer.bias")
+            ops.add_rows(vec, v2, vec)
+            if self.guidance_embed:
+                if guidance is None:
+                    raise ValueError("Didn't get guidance strength for guidance distilled model.")
+                ops.add_rows(vec, self._tembed(guidance, "guidance_in."), vec)
+            # PatchEmbed: Conv3d with kernel = stride = patch -> a Linear on the gathered patches (channel innermost: the flat layout of conv weights)
+            patches = x.to(BF16).reshape(B, C, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B * N, pt * ph * pw * C)
+            img = self._lin(patches, "img_in.proj.weight", "img_in.proj.bias").view(B, N, D)
+            txt = self._refine_text(text_states, t, text_mask)
+        tv = text_mask.sum(1)
+        freqs = None if freqs_cos is None else (freqs_cos, freqs_sin)
+        xx = HunyuanBlocks.forward(self, img, txt, vec, tv, freqs)                      # [B, N + L, D]; carries the adapters' autograd in LoRA mode
+        out = _HYFinal.apply(xx, self, vec, N, (B, tt, th, tw)) if xx.requires_grad else _final_forward(self, xx, vec, N, (B, tt, th, tw))[0]
+        return {"x": out} if return_dict else out
+
+
+def _final_forward(m: "HYVideoDiffusionTransformer", xx, vec, N, dims):
+    B, tt, th, tw = dims
+    D = m.hidden_size
+    pt, ph, pw = m.patch_size
+    oc = m.out_channels
+    dev = xx.device
+    mod = m._lin(m._silu(vec), "final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias", out_dtype=F32)    # shift | scale
+    rows = xx[:, :N].reshape(B * N, D).contiguous()
+    y = torch.empty_like(rows); mean = torch.empty(B * N, dtype=F32, device=dev); rstd = torch.empty_like(mean)
+    ops.ln_modulate_fwd(rows, y, None, None, (mod[:, :D], mod[:, D:], mod[:, :D], mod[:, D:], 2 * D), mean, rstd, D, N, 0, 1e-6)
+    tok = m._lin(y, "final_layer.linear.weight", "final_layer.linear.bias")                                                         # [B N, pt ph pw C]
+    out = tok.view(B, tt, th, tw, oc, pt, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, oc, tt * pt, th * ph, tw * pw)
+    return out, (rows, mean, rstd, mod)
+
+
+class _HYFinal(torch.autograd.Function):
+    """FinalLayer + unpatchify with the gradient w.r.t. the trunk output only (its own weights are frozen)"""
+
+    @staticmethod
+    def forward(ctx, xx, m, vec, N, dims):
+        out, saved = _final_forward(m, xx, vec, N, dims)
+        ctx.m, ctx.N, ctx.dims, ctx.saved, ctx.shape = m, N, dims, saved, xx.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m, N, (B, tt, th, tw) = ctx.m, ctx.N, ctx.dims
+        rows, mean, rstd, mod = ctx.saved
+        D = m.hidden_size
+        pt, ph, pw = m.patch_size
+        oc = m.out_channels
+        dtok = dout.to(BF16).reshape(B, oc, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * N, oc * pt * ph * pw)
+        w = m._w("final_layer.linear.weight")                         # [n_out, D]
+        n_out = w.shape[0]
+        Kp = (n_out + 63) // 64 * 64
+        gp = torch.zeros(B * N, Kp, dtype=BF16, device=dout.device); gp[:, :n_out] = dtok
+        wt = torch.zeros(D, Kp, dtype=BF16, device=dout.device); wt[:, :n_out] = w.t()
+        dy = torch.empty(B * N, D, dtype=BF16, device=dout.device)
+        ops.gemm(gp, wt, dy, None)
+        dx = torch.empty_like(dy)
+        ops.ln_modulate_bwd(dy, rows, mean, rstd, None, (mod[:, D:], mod[:, D:], 2 * D), None, dx, D, N, 0)
+        dxx = torch.zeros(ctx.shape, dtype=BF16, device=dout.device)
+        dxx[:, :N] = dx.view(B, N, D)
+        return dxx, None, None, None, None
 
 
 def flow_matching_loss(pred, x0, noise):

@@ -124,6 +124,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "hunyuan_model.npz"), x=x.numpy(), t=tstep.numpy(), text_states=ts_.numpy(), text_mask=tmask.numpy(),
                         text_states_2=ts2.numpy(), cos=cos2.numpy(), sin=sin2.numpy(), out=y.numpy(), txt_refined=txt_ref.numpy())
     print("hunyuan_model: out", tuple(y.shape), "refined text", tuple(txt_ref.shape))
+    pos = importlib.import_module("videotuna.models.hunyuan.hyvideo_t2v.modules.posemb_layers")
+    rc, rs = pos.get_nd_rotary_pos_embed([16, 56, 56], [3, 4, 6], theta=256, use_real=True, theta_rescale_factor=1)
+    np.savez_compressed(os.path.join(HERE, "hunyuan_rope.npz"), cos=rc.numpy(), sin=rs.numpy())
 
 
 if __name__ == "__main__":

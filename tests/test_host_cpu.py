@@ -485,3 +485,20 @@ def test_encoding_cache_hits_and_resampling():
     small = EncodingCache(max_bytes=4 * 8 * 4 * 2)
     small.prompt_embeds(["x", "yy", "zzz"], enc)
     assert list(small.text) == ["yy", "zzz"]
+
+
+def test_hunyuan_rope_tables_and_remap():
+    """vt355.hunyuan.rope_tables vs the reference's get_nd_rotary_pos_embed (tests/golden/hunyuan_rope.npz: rope_dim_list [16, 56, 56], sizes
+    [3, 4, 6], theta 256); the in-tree denoiser / workflow targets resolve through the remap table"""
+    import numpy as np
+    from vt355.config import get_obj_from_str
+    from vt355.hunyuan import HYVideoDiffusionTransformer, HunyuanVideoFlow, rope_tables
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hunyuan_rope.npz"))
+    cos, sin = rope_tables((3, 4, 6))
+    assert np.allclose(cos.numpy(), g["cos"], atol=1e-6) and np.allclose(sin.numpy(), g["sin"], atol=1e-6)
+    assert get_obj_from_str("videotuna.models.hunyuan.hyvideo_t2v.modules.models.HYVideoDiffusionTransformer") is HYVideoDiffusionTransformer
+    assert get_obj_from_str("videotuna.models.hunyuan.hyvideo_t2v.hunyuanvideo.HunyuanVideoWorkFlow") is HunyuanVideoFlow
+    m = HYVideoDiffusionTransformer(in_channels=4, hidden_size=256, heads_num=2, mm_double_blocks_depth=1, mm_single_blocks_depth=1,
+                                    text_states_dim=64, text_states_dim_2=32, lora_rank=4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 1, 4, 4), torch.zeros(1))                       # no CPU fallback

@@ -429,3 +429,32 @@ def test_whole_transformer_lora_training_step(dev):
     assert torch.isfinite(ts.flat).all() and (ts.flat - before).abs().max().item() > 0
     with pytest.raises(NotImplementedError):
         m.enable_training()
+
+
+def test_hunyuan_flow_training_step(dev):
+    """HunyuanVideoFlow.training_step (hunyuanvideo.py:883-971): sigma from the table, x_t, flow-matching loss, backward into the adapters,
+    optimizer step; loss_from with a fixed sigma / noise equals the formula evaluated on the model's own output"""
+    from vt355.hunyuan import HunyuanVideoFlow
+    HO, m, base = _model(dev, lora_rank=4)
+    flow = HunyuanVideoFlow(model=m, learning_rate=1e-3).to(dev)
+    opt = flow.configure_optimizers()
+    g = np.load(os.path.join(G, "hunyuan_model.npz"))
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    batch = {"latents": T("x"), "prompt_embeds": T("text_states"), "prompt_attention_mask": T("text_mask"), "pooled_prompt_embeds": T("text_states_2")}
+    torch.manual_seed(0)
+    loss = flow.training_step(batch)
+    loss.backward()
+    ts = m.lora.train_state
+    assert torch.isfinite(loss) and ts.grad.abs().max().item() > 0
+    opt.step()
+    sigma = torch.tensor([0.25, 0.75], device=dev)
+    noise = torch.randn(g["x"].shape, device=dev)
+    l2 = flow.loss_from(batch["latents"], batch["prompt_embeds"], batch["prompt_attention_mask"], batch["pooled_prompt_embeds"], sigma, noise)
+    with torch.no_grad():
+        s5 = sigma.view(-1, 1, 1, 1, 1)
+        xt = ((1 - s5) * batch["latents"] + s5 * noise).to(BF)
+        cos, sin = flow._rope[(3, 4, 6)]
+        out = m(xt, (sigma * 1000).long(), text_states=batch["prompt_embeds"], text_mask=batch["prompt_attention_mask"],
+                text_states_2=batch["pooled_prompt_embeds"], freqs_cos=cos, freqs_sin=sin, return_dict=False)
+        want = ((out.float() - (noise - batch["latents"])) ** 2).mean()
+    assert abs(l2.item() - want.item()) < 1e-4 * want.item()

@@ -29,6 +29,9 @@ TARGET_REMAP = {
     "videotuna.models.opensora.models.stdit.stdit.STDiT": "vt355.stdit.STDiT",
     "videotuna.models.opensora.models.iddpm3d.LatentDiffusion": "vt355.stdit.OpenSoraFlow",
     "videotuna.models.opensora.models.iddpm3d.OpenSoraScheduler": "vt355.stdit.OpenSoraScheduler",
+    # HunyuanVideo (in-tree denoiser class; the shipped LoRA recipe's diffusers class has no key map here)
+    "videotuna.models.hunyuan.hyvideo_t2v.modules.models.HYVideoDiffusionTransformer": "vt355.hunyuan.HYVideoDiffusionTransformer",
+    "videotuna.models.hunyuan.hyvideo_t2v.hunyuanvideo.HunyuanVideoWorkFlow": "vt355.hunyuan.HunyuanVideoFlow",
 }
 _NON_CTOR_KEYS = ("load_dtype",)       # consumed by the workflow, not by the class (cogvideo_pl.py:125-132)
 

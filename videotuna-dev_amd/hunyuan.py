@@ -791,6 +791,82 @@ class _HYFinal(torch.autograd.Function):
         return dxx, None, None, None, None
 
 
+def rope_tables(sizes, rope_dim_list=(16, 56, 56), theta: float = 256.0):
+    """get_nd_rotary_pos_embed(rope_dim_list, sizes, theta, use_real=True) of modules/posemb_layers.py:191-258 as inference.py:470-495 calls it
+    (rope_sizes = latent size // patch size, theta = args.rope_theta = 256): (cos, sin) fp32 [prod(sizes), sum(rope_dim_list)], every
+    frequency repeated for its (2i, 2i+1) pair; axis i contributes rope_dim_list[i] columns from its own coordinate."""
+    grids = torch.meshgrid(*[torch.arange(n, dtype=torch.float32) for n in sizes], indexing="ij")
+    cos, sin = [], []
+    for dim, gr in zip(rope_dim_list, grids):
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        a = torch.outer(gr.reshape(-1), freqs)
+        cos.append(a.cos().repeat_interleave(2, dim=1)); sin.append(a.sin().repeat_interleave(2, dim=1))
+    return torch.cat(cos, 1), torch.cat(sin, 1)
+
+
+class HunyuanVideoFlow(torch.nn.Module):
+    """training_step of HunyuanVideoWorkFlow (hyvideo_t2v/hunyuanvideo.py:883-971) around vt355's denoiser: sigma drawn uniformly from the
+    scheduler's table (flow_weighting_scheme "none"), timesteps = (sigma * 1000).long(), x_t = (1 - sigma) x0 + sigma eps, target eps - x0, mean
+    squared error.  Batches come pre-encoded -- {"latents" [B, C, T, H, W], "prompt_embeds" [B, L, text_dim], "prompt_attention_mask" [B, L],
+    "pooled_prompt_embeds" [B, text_dim_2]} -- the causal VAE and the LLM / CLIP text encoders of that workflow are frozen neighbours outside
+    this path.  The scheduler's sigma table is linspace(1, 1/N, N) with an optional shift (the checkpoint's scheduler config is not available
+    offline: flow_shift is a constructor argument)."""
+
+    def __init__(self, denoiser_config=None, model: Optional[HYVideoDiffusionTransformer] = None, num_train_timesteps: int = 1000,
+                 flow_shift: float = 1.0, learning_rate: float = 1e-5, rope_theta: float = 256.0, **unused):
+        super().__init__()
+        if model is None:
+            from .config import instantiate_from_config
+            model = instantiate_from_config(denoiser_config)
+        self.model, self.learning_rate, self.rope_theta = model, learning_rate, rope_theta
+        s = torch.linspace(1.0, 1.0 / num_train_timesteps, num_train_timesteps)
+        self.register_buffer("sigmas", flow_shift * s / (1.0 + (flow_shift - 1.0) * s), persistent=False)
+        self._rope = {}
+
+    def configure_optimizers(self):
+        from .optim import FusedAdamW
+        ts = self.model.enable_lora_training()
+        return FusedAdamW(ts.params, lr=self.learning_rate, fullft_state=ts)
+
+    def loss_from(self, x0, prompt_embeds, mask, pooled, sigma, noise, guidance=None):
+        dev = x0.device
+        B, C, T, Hh, Ww = x0.shape
+        pt, ph, pw = self.model.patch_size
+        key = (T // pt, Hh // ph, Ww // pw)
+        if key not in self._rope:
+            cos, sin = rope_tables(key, theta=self.rope_theta)
+            self._rope[key] = (cos.to(dev), sin.to(dev))
+        s5 = sigma.view(-1, 1, 1, 1, 1).float()
+        xt = ((1.0 - s5) * x0.float() + s5 * noise.float()).to(BF16)
+        t = (sigma * 1000.0).long()
+        out = self.model(xt, t, text_states=prompt_embeds, text_mask=mask, text_states_2=pooled, freqs_cos=self._rope[key][0],
+                         freqs_sin=self._rope[key][1], guidance=guidance, return_dict=False)
+        return _FlowLoss.apply(out, x0.float(), noise.float())
+
+    def training_step(self, batch, batch_idx=0):
+        x0 = batch["latents"]
+        B = x0.shape[0]
+        idx = (torch.rand(B, device=x0.device) * self.sigmas.numel()).long().clamp_(max=self.sigmas.numel() - 1)
+        sigma = self.sigmas.to(x0.device)[idx]
+        guidance = torch.full((B,), 1000.0, device=x0.device) if self.model.guidance_embed else None
+        return self.loss_from(x0, batch["prompt_embeds"], batch["prompt_attention_mask"], batch["pooled_prompt_embeds"], sigma,
+                              torch.randn_like(x0, dtype=torch.float32), guidance)
+
+
+class _FlowLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, x0, noise):
+        loss, dpred = flow_matching_loss(out.contiguous().view(out.shape[0], -1), x0.reshape(out.shape[0], -1), noise.reshape(out.shape[0], -1))
+        ctx.save_for_backward(dpred)
+        ctx.shape = out.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred.float() * g).to(BF16).view(ctx.shape), None, None
+
+
 def flow_matching_loss(pred, x0, noise):
     """mean_b mean (pred - (noise - x0))^2 (hunyuanvideo.py:963-970, weights 1); pred bf16, x0 / noise fp32 -> (loss fp32 [1], dpred bf16)"""
     target = torch.empty_like(x0)

@@ -21,6 +21,9 @@ struct Attn128Params {
 };
 
 #define A128_NEG (-1.0e30f)
+#ifndef A128_PF
+#define A128_PF 1        // 1 = software-pipelined operand reads in the key-stationary backward (0: the compiler's order)
+#endif
 #ifndef A128_ABL_NOATOM
 #define A128_ABL_NOATOM 0
 #endif
@@ -114,6 +117,25 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(Attn128Params p) {
         f32x16 st[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
+#if A128_PF
+        // operand reads four MFMAs ahead (ring of four), order pinned: index i = (plane, k-step, key sub-tile) of S^T, j = (key sub-tile, s2, plane,
+        // d-tile) of O^T += V^T P^T -- the last four S^T MFMAs already carry the first V^T fragments
+        bf16x8 kfr[4], vtr[4];
+        auto rd_k = [&](int i) { kfr[i & 3] = *(const bf16x8*)(base + (i >> 3) * 8192 + (i & 1) * 4096 + kfo[(i >> 1) & 3]); };
+        auto rd_v = [&](int j) {
+            const char* vp = base + 16384 + ((j >> 1) & 1) * 8192 + vfo[j & 1] + ((j >> 3) * 32 + ((j >> 2) & 1) * 16) * 128;
+            vtr[j & 3] = a128_tr_pair(vp, vp + 8 * 128);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rd_k(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[i & 3], qf[i >> 3][(i >> 1) & 3], st[i & 1], 0, 0, 0);
+            if (i + 4 < 16) rd_k(i + 4); else rd_v(i - 12);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -123,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(Attn128Params p) {
                     const bf16x8 kf = *(const bf16x8*)(base + pl * 8192 + kt2 * 4096 + kfo[s]);
                     st[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[pl][s], st[kt2], 0, 0, 0);
                 }
+#endif
         if ((t + 1) * 64 > klen) {
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -155,6 +178,19 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(Attn128Params p) {
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o_acc[c][i] *= alpha;
+#if A128_PF
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kt2 = j >> 3, s2 = (j >> 2) & 1, c = j & 3;                   // c = 2 plane + d-tile
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)st[kt2][8 * s2 + e];
+            o_acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vtr[j & 3], pf, o_acc[c], 0, 0, 0);
+            if (j + 4 < 16) rd_v(j + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -170,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn128_fwd_kernel(Attn128Params p) {
                         o_acc[2 * pl + dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a128_tr_pair(vp, vp + 8 * 128), pf, o_acc[2 * pl + dt], 0, 0, 0);
                     }
             }
+#endif
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -372,6 +409,75 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
         const char* tile = smem + B128_QTILE + buf * 32768;          // Q planes at +0, +8192; dO planes at +16384, +24576
         const float* lsel = (const float*)(smem + B128_STAT + buf * 512);
         char* dsimg = smem + B128_DSIMG + buf * 16384;
+#if A128_PF
+        {
+            // one wave per SIMD: nobody else covers an LDS round trip, so every operand read is issued four MFMA pairs ahead (rings of four
+            // row-operand pairs and four transposed-operand groups), the issue order pinned with sched_barrier fences -- the r02 recipe of
+            // attn_bwd.hip.  Index i = (plane, k-step) of the S / dP products, j = (s2, plane, d-tile) of the dV / dK products.
+            f32x16 sacc[2], pacc[2];
+            bf16x8 qa[4], doa[4], doT[4], qT[4];
+            auto rd_init = [&](int qs, int gg) {
+                const f32x4 a = *(const f32x4*)(lsel + 32 * qs + 8 * gg + 4 * h);
+                const f32x4 c = *(const f32x4*)(lsel + 64 + 32 * qs + 8 * gg + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sacc[qs][4 * gg + e] = a[e] + kmask; pacc[qs][4 * gg + e] = c[e]; }
+            };
+            auto rd_rows = [&](int qs, int i) {
+                qa[i & 3] = *(const bf16x8*)(tile + (i >> 2) * 8192 + qs * 4096 + rowrd[i & 3]);
+                doa[i & 3] = *(const bf16x8*)(tile + 16384 + (i >> 2) * 8192 + qs * 4096 + rowrd[i & 3]);
+            };
+            auto rd_tr = [&](int qs, int j) {                 // j = 4 s2 + 2 pl + dt
+                const int ro = (32 * qs + 16 * (j >> 2)) * 128, pl = (j >> 1) & 1, dt = j & 1;
+                const char* qimg = tile + pl * 8192 + ro, *doimg = tile + 16384 + pl * 8192 + ro;
+                doT[j & 3] = a128_tr_pair(doimg + trA[dt][0], doimg + trA[dt][1]);
+                qT[j & 3] = a128_tr_pair(qimg + trA[dt][0], qimg + trA[dt][1]);
+            };
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) rd_init(0, gg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rd_rows(0, i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[i & 3], kf[i >> 2][i & 3], sacc[qs], 0, 0, 0);
+                    pacc[qs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[i & 3], vf[i >> 2][i & 3], pacc[qs], 0, 0, 0);
+                    if (i + 4 < 8) rd_rows(qs, i + 4); else rd_tr(qs, i - 4);          // into the slot these MFMAs just read
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                unsigned pw[8], dw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p0 = __builtin_amdgcn_exp2f(sacc[qs][2 * i] * sc);
+                    const float p1 = __builtin_amdgcn_exp2f(sacc[qs][2 * i + 1] * sc);
+                    pw[i] = pack2(p0, p1);
+                    dw[i] = pack2(p0 * pacc[qs][2 * i], p1 * pacc[qs][2 * i + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int s2 = j >> 2, pl = (j >> 1) & 1, dt = j & 1;
+                    const u32x4 pb4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+                    const u32x4 db4 = {dw[4 * s2], dw[4 * s2 + 1], dw[4 * s2 + 2], dw[4 * s2 + 3]};
+                    dv_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[j & 3], __builtin_bit_cast(bf16x8, pb4), dv_acc[pl][dt], 0, 0, 0);
+                    dk_acc[pl][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[j & 3], __builtin_bit_cast(bf16x8, db4), dk_acc[pl][dt], 0, 0, 0);
+                    if (j + 4 < 8) rd_tr(qs, j + 4);
+                    else if (qs == 0) { rd_init(1, j - 4); rd_rows(1, j - 4); }         // the other q-half's first reads ride under these MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (DQ) {
+                    char* drow = dsimg + (32 * w + r) * 128 + 8 * h;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const u32x2 two = {dw[2 * gg], dw[2 * gg + 1]};
+                        *(u32x2*)(drow + (((4 * qs + gg) ^ fr) << 4)) = two;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             f32x16 sacc, pacc;
@@ -423,6 +529,7 @@ __global__ __launch_bounds__(256, 1) void attn128_bwd_kernel(Attn128Params p) {
                 }
             }
         }
+#endif
         stage_finish(t + 1, DQ ? t == 0 : true);
         __syncthreads();
         stage(t + 2);

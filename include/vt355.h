@@ -352,7 +352,7 @@ int vt_quantize_fp8(const void* x, long long ldx, void* y, long long ldy, long l
  * [M, 3*H*128] projection, rotary embedding of the first S_rope positions of every sample (image tokens; cos / sin fp32 [S_rope, 128] | NULL),
  * and the scatter of q^ | k^ | v into the joint [image; text] sequence: out row = (m / L) * Lout + row_off + m % L.  rstd fp32 [M, 2H].
  * Replaces: img_attn_q_norm / img_attn_k_norm / apply_rotary_emb / torch.cat of MMDoubleStreamBlock.forward and q_norm / k_norm / the
- * sliced rotary of MMSingleStreamBlock.forward (videotuna/models/hunyuan/hyvideo_t2v/modules/models.py:166-196, 351-361). */
+ * sliced rotary of MMSingleStreamBlock.forward (videotuna/models/hunyuan/hyvideo_t2v/modules/models.py:166-196, 351-361). * Backward: dgq / dgk fp32 [128] accumulated (both NULL: the norm weights are frozen, the reduction is skipped). */
 int vt_qk_rmsnorm_rope128_fwd(const void* qkv, long long ld, void* out, long long ldo, const void* gq, const void* gk, float* rstd,
                               const float* rope_cos, const float* rope_sin, long long M, int H, int L, int Lout, int row_off,
                               int S_rope, float eps, void* stream);

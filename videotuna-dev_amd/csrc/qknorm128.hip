@@ -60,10 +60,16 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_bwd_kernel(const bf16_t* 
                                                                  long long ldd, const bf16_t* gq, const bf16_t* gk, const float* rstd, const float* cs,
                                                                  const float* sn, float* dgq, float* dgk, long long M, int H, int L, int Lout,
                                                                  int row_off, int S_rope) {
-    __shared__ float red[2][128];
-    for (int i = threadIdx.x; i < 256; i += 256) red[i >> 7][i & 127] = 0.f;
-    __syncthreads();
+    // dgq / dgk: every 16-lane group leaves its unit's 128 products in its own LDS row (plain stores -- the first version added them with LDS
+    // atomics into one shared row and spent 6x the kernel's memory time on the conflicts), the block sums the 16 rows and adds once per column;
+    // dgq == nullptr (frozen norm weights, LoRA mode): skipped altogether
+    __shared__ float red[16][256];
+    const bool want = dgq != nullptr;
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    if (want) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[grp][sub * 16 + j] = 0.f;
+    }
     const long long unit = (long long)blockIdx.x * 16 + grp;
     const long long units = M * 3 * H;
     if (unit < units) {
@@ -94,7 +100,10 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_bwd_kernel(const bf16_t* 
             const float r = rstd[m * 2 * H + which * H + hh];
             float dot = 0.f, dxn[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { dxn[j] = dy[j] * g[j]; dot += dxn[j] * x[j]; atomicAdd(&red[which][sub * 8 + j], dy[j] * x[j] * r); }
+            for (int j = 0; j < 8; ++j) {
+                dxn[j] = dy[j] * g[j]; dot += dxn[j] * x[j];
+                if (want) red[grp][which * 128 + sub * 8 + j] = dy[j] * x[j] * r;
+            }
             dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
             const float k3 = r * r * r * dot * (1.0f / 128.0f);
             float dx[8];
@@ -103,9 +112,16 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_bwd_kernel(const bf16_t* 
             *(u32x4*)(dqkv + m * ldd + col) = pack8(dx);
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 128) { atomicAdd(dgq + threadIdx.x, red[0][threadIdx.x]); }
-    else { atomicAdd(dgk + threadIdx.x - 128, red[1][threadIdx.x - 128]); }
+    if (want) {
+        __syncthreads();
+        float sum = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) sum += red[gi][threadIdx.x];
+        if (sum != 0.f) {
+            if (threadIdx.x < 128) atomicAdd(dgq + threadIdx.x, sum);
+            else atomicAdd(dgk + threadIdx.x - 128, sum);
+        }
+    }
 }
 
 extern "C" int vt_qk_rmsnorm_rope128_fwd(const void* qkv, long long ld, void* out, long long ldo, const void* gq, const void* gk, float* rstd,
@@ -123,7 +139,7 @@ extern "C" int vt_qk_rmsnorm_rope128_fwd(const void* qkv, long long ld, void* ou
 extern "C" int vt_qk_rmsnorm_rope128_bwd(const void* dout, long long lddo, const void* qkv, long long ld, void* dqkv, long long ldd, const void* gq,
                                          const void* gk, const float* rstd, const float* rope_cos, const float* rope_sin, float* dgq, float* dgk,
                                          long long M, int H, int L, int Lout, int row_off, int S_rope, void* stream) {
-    if (M <= 0 || H <= 0 || L <= 0 || (M % L) || Lout < row_off + L || (ld % 8) || (lddo % 8) || (ldd % 8) || dgq == nullptr || dgk == nullptr)
+    if (M <= 0 || H <= 0 || L <= 0 || (M % L) || Lout < row_off + L || (ld % 8) || (lddo % 8) || (ldd % 8) || ((dgq == nullptr) != (dgk == nullptr)))
         return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)qkv) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) return VT_ERR_BAD_ALIGN;
     const long long units = M * 3 * H;

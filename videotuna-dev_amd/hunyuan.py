@@ -226,7 +226,6 @@ class _HYRun(_STRun):
         self.lora = model.lora
         self.LP = _packed_lora(model) if model.lora is not None else None
         self.lts = None if model.lora is None else model.lora.train_state
-        self._dummy = torch.zeros(256, dtype=F32, device=self.dev)       # sink of parameter gradients nobody trains (frozen q / k norms)
 
     # ---- frozen block weights (LoRA mode: self.ts is None): no gradient buffers, no dW GEMMs ----
     def G(self, name):
@@ -417,9 +416,7 @@ class _HYRun(_STRun):
         if self.save:
             def bwd_qkv_to_joint():
                 dq = self.E(M, qkv.d.shape[1])
-                frozen = self.ts is None
-                ops.qk_rmsnorm_rope128_bwd(djoint_ref[0], qkv.d, dq, gq, gk, rstd, self._dummy[:128] if frozen else self.G(pre_q),
-                                           self._dummy[128:] if frozen else self.G(pre_k), H, L, Lj, off, rope)
+                ops.qk_rmsnorm_rope128_bwd(djoint_ref[0], qkv.d, dq, gq, gk, rstd, self.G(pre_q), self.G(pre_k), H, L, Lj, off, rope)   # frozen: None
                 qkv.g = dq
             self.tape.append(bwd_qkv_to_joint)
 

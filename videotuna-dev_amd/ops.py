@@ -832,7 +832,7 @@ def qk_rmsnorm_rope128_bwd(dout, qkv, dqkv, gq, gk, rstd, dgq, dgk, H: int, L: i
     _req(dout, BF16, "dout", 2); _req(qkv, BF16, "qkv", 2); _req(dqkv, BF16, "dqkv", 2)
     cos, sin = (None, None) if rope is None else rope
     check(load_library().vt_qk_rmsnorm_rope128_bwd(dout.data_ptr(), dout.stride(0), qkv.data_ptr(), qkv.stride(0), dqkv.data_ptr(), dqkv.stride(0),
-                                                   gq.data_ptr(), gk.data_ptr(), rstd.data_ptr(), _p(cos), _p(sin), dgq.data_ptr(), dgk.data_ptr(),
+                                                   gq.data_ptr(), gk.data_ptr(), rstd.data_ptr(), _p(cos), _p(sin), _p(dgq), _p(dgk),
                                                    qkv.shape[0], H, L, Lout, row_off, 0 if cos is None else cos.shape[0], _stream()),
           "vt_qk_rmsnorm_rope128_bwd")
 

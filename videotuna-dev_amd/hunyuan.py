@@ -447,7 +447,7 @@ class _HYRun(_STRun):
         D, H = self.m.hidden_size, self.m.heads_num
         C, Lj = D, Li + Lt
         bs = 6 * D
-        joint = torch.zeros(B * Lj, 3 * C, dtype=BF16, device=self.dev)
+        joint = self.E(B * Lj, 3 * C)                         # every row is written by the two scatters below
         dj = [None]
         streams = {}
         for s, x, L, off, rp in (("img", img, Li, 0, rope), ("txt", txt, Lt, Li, None)):
@@ -476,7 +476,7 @@ class _HYRun(_STRun):
             if self.save:
                 def bwd_split(av=av, off=off, L=L, ov=ov):
                     if ov.g is None:
-                        ov.g = torch.zeros(B * Lj, C, dtype=BF16, device=self.dev)
+                        ov.g = self.E(B * Lj, C)              # both streams' splits fill all of it
                     ov.g.view(B, Lj, C)[:, off:off + L].copy_(av.g.view(B, L, C))
                 self.tape.append(bwd_split)
             x1 = self.glinear(av, pre + s + "_attn_proj.weight", pre + s + "_attn_proj.bias", x, sl(2), dsl(2), L, bs)

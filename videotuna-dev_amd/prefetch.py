@@ -122,17 +122,18 @@ class EncodingCache:
     def latents(self, indices, videos, posterior: Callable[[torch.Tensor], Any], scaling_factor: float, generator=None) -> torch.Tensor:
         """posterior(video [1,3,T,H,W]) -> object with .mean / .std (vt355.vae.DiagonalGaussianDistribution)"""
         out = []
-        for i, v in zip(indices, videos):
+        for n, i in enumerate(indices):                                              # videos[n] is only touched on a miss (it may be lazy)
             key = int(i)
             if key not in self.moments:
                 self.misses["latent"] += 1
+                v = videos[n]
                 d = posterior(v.unsqueeze(0) if v.dim() == 4 else v)
                 m, sdev = d.mean.detach().clone(), d.std.detach().clone()
                 self._room((m.numel() + sdev.numel()) * m.element_size())
                 self.moments[key] = (m, sdev)
             else:
                 self.hits["latent"] += 1
-            m, sdev = self.moments[key]
+                m, sdev = self.moments[key]
             eps = torch.randn(m.shape, generator=generator, device=m.device, dtype=m.dtype)
             out.append((m + sdev * eps) * scaling_factor)
         return torch.cat(out, 0)

@@ -98,3 +98,54 @@ def test_device_core_refuses_cpu():
     q = torch.zeros(1, 4, 2, 128, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         sp.device_core(q, q, q, None)
+
+
+# ---- the explicit four-step exchange the tape engine uses (partial-sum convention) ----
+def _worker_steps(rank, world, port, res):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vt355 import sp
+    img, txt, gi, gt, tv, Li = _inputs()
+    B, _, H, d = img[0].shape
+    Lt = txt[0].shape[1]
+    n = Li // world
+    sl = slice(rank * n, (rank + 1) * n)
+    # local joint buffer: rows [my image rows ; text], columns [q | k | v] x all heads
+    joint = torch.cat([torch.cat([img[i][:, sl], txt[i]], 1).reshape(B, n + Lt, H * d) for i in range(3)], -1).reshape(B * (n + Lt), 3 * H * d)
+    j2 = sp.joint_to_heads(joint, B, n, Lt, H, d).requires_grad_(True)
+    h = H // world
+    q, k, v = (j2[:, :, i * h * d:(i + 1) * h * d].reshape(B, Li + Lt, h, d) for i in range(3))
+    o2 = _dense_core(q, k, v, tv + Li).reshape(B, Li + Lt, h * d)
+    pad = 3                                                                          # the engine's output rows may be strided
+    obuf = torch.zeros(B * (n + Lt), H * d + pad, dtype=torch.float64)
+    o3 = obuf.as_strided((B, n + Lt, H * d), ((n + Lt) * (H * d + pad), H * d + pad, 1))
+    sp.heads_to_rows(o2.detach(), o3, B, n, Lt, H, d)
+    # incoming gradient: image rows mine; text rows a PARTIAL share (rank-dependent split of the full text gradient)
+    share = (0.3, 0.7)[rank]
+    g3 = torch.cat([gi[:, sl], gt * share], 1).reshape(B, n + Lt, H * d)
+    go2 = sp.rows_grad_to_heads(g3, B, n, Lt, H, d)
+    o2.backward(go2)
+    dj = sp.heads_grad_to_joint(j2.grad, B, n, Lt, H, d)
+    res[rank] = (o3.clone(), dj.view(B, n + Lt, 3, H, d).clone())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_tape_engine_exchange_world2_matches_unsharded():
+    mgr = mp.Manager(); res = mgr.dict()
+    mp.spawn(_worker_steps, args=(2, _free_port(), res), nprocs=2, join=True)
+    out, grads = _reference()
+    B, Li, Lt, H, d = 2, 12, 5, 4, 8
+    n = Li // 2
+    valid = torch.ones(B, Lt, dtype=torch.bool); valid[1, 2:] = False
+    for r in (0, 1):
+        o3, dj = res[r]
+        o3 = o3.view(B, n + Lt, H, d)
+        assert torch.allclose(o3[:, :n], out[:, r * n:(r + 1) * n], atol=1e-12)
+        assert torch.allclose(o3[:, n:][valid], out[:, Li:][valid], atol=1e-12)             # every rank holds the whole text output
+        for i in range(3):
+            assert torch.allclose(dj[:, :n, i], grads[i][:, r * n:(r + 1) * n], atol=1e-12), ("image operand", i, r)
+    for i in range(3):                                                                      # text gradients: partial per rank, their sum is the gradient
+        tot = res[0][1][:, n:, i] + res[1][1][:, n:, i]
+        assert torch.allclose(tot, grads[3 + i], atol=1e-12), ("text operand", i)
+        h = H // 2
+        assert res[0][1][:, n:, i, h:].abs().max() == 0 and res[1][1][:, n:, i, :h].abs().max() == 0

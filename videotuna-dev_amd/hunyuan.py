@@ -21,6 +21,7 @@ from types import SimpleNamespace
 from typing import Dict, Optional
 
 import torch
+import torch.distributed
 
 from . import ops
 from .ops import BF16, EPI_BIAS_GELU, EPI_DGELU, EPI_GATED_RES
@@ -118,6 +119,21 @@ class HunyuanBlocks(FlatParamModule):
         self._setup_flat({**(shapes_before or {}), **sh, **(shapes_after or {})})
         # LoRA mode: the block weights stay frozen (no fp32 master, no gradients, no dW GEMMs); only the adapters train
         self.lora = _HYLora(hidden_size, mm_double_blocks_depth, mm_single_blocks_depth, lora_rank, lora_alpha) if lora_rank > 0 else None
+        self.sp_group = None
+
+    def set_sequence_parallel(self, group):
+        """Ulysses sequence parallelism over ``group`` (vt355.sp; SURVEY 8(e), the 119 k-token 720p sequence): ``img`` and ``freqs_cis`` passed
+        to forward are then THIS RANK'S contiguous 1/P of the image rows, the text rows are replicated, and the result holds the local image
+        rows followed by the text rows.  Every row-wise kernel runs on the local rows; the joint attention exchanges rows for heads around
+        ``vt_attn128`` (all rows, H/P heads).  Gradients follow sp.py's partial-sum convention: text-row, modulation-vector and parameter
+        gradients of a rank are partial, the group SUM is the gradient (so a data-parallel reducer that averages over all ranks, with every
+        rank back-propagating the mean loss of its own rows, yields the gradient of the overall mean).  ``None`` switches it off."""
+        if group is not None:
+            import torch.distributed as dist
+            if self.heads_num % dist.get_world_size(group):
+                raise ValueError(f"{self.heads_num} heads do not split over {dist.get_world_size(group)} ranks")
+        self.sp_group = group
+        return self
 
     def init_weights(self, seed: int = 0):
         g = torch.Generator().manual_seed(seed)
@@ -226,6 +242,11 @@ class _HYRun(_STRun):
         self.lora = model.lora
         self.LP = _packed_lora(model) if model.lora is not None else None
         self.lts = None if model.lora is None else model.lora.train_state
+        self.sp = model.sp_group
+        self.spP = 1
+        if self.sp is not None:
+            import torch.distributed as dist
+            self.spP = dist.get_world_size(self.sp)
 
     # ---- frozen block weights (LoRA mode: self.ts is None): no gradient buffers, no dW GEMMs ----
     def G(self, name):
@@ -424,16 +445,37 @@ class _HYRun(_STRun):
         """attention over the joint sequence; o_out: [B*Lj, >= C] buffer view (row stride may exceed C); the backward fills djoint_ref[0]"""
         H = self.m.heads_num
         C = H * 128
-        j3 = joint.view(B, Lj, 3 * C)
         o3 = o_out.view(B, Lj, o_out.shape[1]) if o_out.is_contiguous() else o_out.as_strided((B, Lj, C), (Lj * o_out.stride(0), o_out.stride(0), 1))
-        lse = self.E(B, H, Lj, dt=F32)
         scale = 128 ** -0.5
-        ops.attn128_fwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], lse, H, scale, kv_len=kv_len)
+        rows = lambda g: g.view(B, Lj, g.shape[1]) if g.is_contiguous() else g.as_strided((B, Lj, C), (Lj * g.stride(0), g.stride(0), 1))
         ov = _Var(o_out)
+        if self.spP > 1:
+            # Ulysses: rows <-> heads around the local attention (sp.py); Lj = local image rows + text rows, the attention sees every row
+            from . import sp
+            Lt = Lj - self._Lil
+            geo = (B, self._Lil, Lt, H, 128, self.sp)
+            h, S2 = H // self.spP, self._Lil * self.spP + Lt
+            c2 = h * 128
+            j2 = sp.joint_to_heads(joint, *geo)                                       # [B, S2, 3 c2]
+            o2 = self.E(B, S2, c2)
+            lse = self.E(B, h, S2, dt=F32)
+            ops.attn128_fwd(j2[:, :, :c2], j2[:, :, c2:2 * c2], j2[:, :, 2 * c2:], o2, lse, h, scale, kv_len=kv_len)
+            sp.heads_to_rows(o2, o3[:, :, :C], *geo)
+            if self.save:
+                def bwd_joint_attention_sp():
+                    go2 = sp.rows_grad_to_heads(rows(ov.g)[:, :, :C], *geo)
+                    dj2 = self.E(B, S2, 3 * c2)
+                    ops.attn128_bwd(j2[:, :, :c2], j2[:, :, c2:2 * c2], j2[:, :, 2 * c2:], o2, go2, lse, dj2[:, :, :c2], dj2[:, :, c2:2 * c2],
+                                    dj2[:, :, 2 * c2:], h, scale, kv_len=kv_len)
+                    djoint_ref[0] = sp.heads_grad_to_joint(dj2, *geo)
+                self.tape.append(bwd_joint_attention_sp)
+            return ov
+        j3 = joint.view(B, Lj, 3 * C)
+        lse = self.E(B, H, Lj, dt=F32)
+        ops.attn128_fwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], lse, H, scale, kv_len=kv_len)
         if self.save:
             def bwd_joint_attention():
-                g = ov.g
-                g3 = g.view(B, Lj, g.shape[1]) if g.is_contiguous() else g.as_strided((B, Lj, C), (Lj * g.stride(0), g.stride(0), 1))
+                g3 = rows(ov.g)
                 dj = self.E(B * Lj, 3 * C)
                 d3 = dj.view(B, Lj, 3 * C)
                 ops.attn128_bwd(j3[:, :, :C], j3[:, :, C:2 * C], j3[:, :, 2 * C:], o3[:, :, :C], g3[:, :, :C], lse, d3[:, :, :C], d3[:, :, C:2 * C],
@@ -563,7 +605,8 @@ class _HYRun(_STRun):
         m = self.m
         B, Li, D = img.shape
         Lt = txt.shape[1]
-        kv_len = (txt_valid.to(self.dev).to(torch.int32) + Li).contiguous()
+        self._Lil = Li                                                               # local image rows; the attention's keys: all P shards + valid text
+        kv_len = (txt_valid.to(self.dev).to(torch.int32) + Li * self.spP).contiguous()
         rope = None if freqs is None else (freqs[0].to(self.dev, F32).contiguous(), freqs[1].to(self.dev, F32).contiguous())
         self._vec = vec.to(BF16).contiguous()
         sv = self.E(B, D); ops.silu(self._vec, sv)
@@ -732,17 +775,40 @@ class HYVideoDiffusionTransformer(HunyuanBlocks):
                     raise ValueError("Didn't get guidance strength for guidance distilled model.")
                 ops.add_rows(vec, self._tembed(guidance, "guidance_in."), vec)
             # PatchEmbed: Conv3d with kernel = stride = patch -> a Linear on the gathered patches (channel innermost: the flat layout of conv weights)
-            patches = x.to(BF16).reshape(B, C, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B * N, pt * ph * pw * C)
-            img = self._lin(patches, "img_in.proj.weight", "img_in.proj.bias").view(B, N, D)
+            patches = x.to(BF16).reshape(B, C, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, N, pt * ph * pw * C)
+            lo, Nl = self._sp_rows(N)
+            img = self._lin(patches[:, lo:lo + Nl].reshape(B * Nl, -1), "img_in.proj.weight", "img_in.proj.bias").view(B, Nl, D)
             txt = self._refine_text(text_states, t, text_mask)
         tv = text_mask.sum(1)
-        freqs = None if freqs_cos is None else (freqs_cos, freqs_sin)
-        xx = HunyuanBlocks.forward(self, img, txt, vec, tv, freqs)                      # [B, N + L, D]; carries the adapters' autograd in LoRA mode
-        out = _HYFinal.apply(xx, self, vec, N, (B, tt, th, tw)) if xx.requires_grad else _final_forward(self, xx, vec, N, (B, tt, th, tw))[0]
+        freqs = None if freqs_cos is None else (freqs_cos[lo:lo + Nl], freqs_sin[lo:lo + Nl])
+        xx = HunyuanBlocks.forward(self, img, txt, vec, tv, freqs)                      # [B, Nl + L, D]; carries the adapters' autograd in LoRA mode
+        tokens = Nl != N
+        dims = (B, tt, th, tw)
+        out = _HYFinal.apply(xx, self, vec, Nl, dims, tokens) if xx.requires_grad else _final_forward(self, xx, vec, Nl, dims, tokens)[0]
         return {"x": out} if return_dict else out
 
+    def _sp_rows(self, N: int):
+        """(first row, row count) of this rank's image tokens: everything without sequence parallelism"""
+        if self.sp_group is None:
+            return 0, N
+        import torch.distributed as dist
+        P, r = dist.get_world_size(self.sp_group), dist.get_rank(self.sp_group)
+        if N % P:
+            raise ValueError(f"{N} image tokens do not split over {P} ranks")
+        return r * (N // P), N // P
 
-def _final_forward(m: "HYVideoDiffusionTransformer", xx, vec, N, dims):
+    def patchify(self, x):
+        """[B, C_out, T, H, W] -> [B, N, C_out pt ph pw]: the token layout of the final layer's output (the inverse of unpatchify, models.py:702-720);
+        under sequence parallelism forward() returns rows ``_sp_rows(N)`` of it"""
+        B, oc, T, Hh, Ww = x.shape
+        pt, ph, pw = self.patch_size
+        tt, th, tw = T // pt, Hh // ph, Ww // pw
+        return x.reshape(B, oc, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, tt * th * tw, oc * pt * ph * pw)
+
+
+def _final_forward(m: "HYVideoDiffusionTransformer", xx, vec, N, dims, tokens: bool = False):
+    """xx [B, N + L, D] -> FinalLayer on the N image rows -> unpatchify; ``tokens``: the rows are one rank's share of the grid, return them as
+    tokens [B, N, C_out pt ph pw] (HYVideoDiffusionTransformer.patchify's layout)"""
     B, tt, th, tw = dims
     D = m.hidden_size
     pt, ph, pw = m.patch_size
@@ -753,6 +819,8 @@ def _final_forward(m: "HYVideoDiffusionTransformer", xx, vec, N, dims):
     y = torch.empty_like(rows); mean = torch.empty(B * N, dtype=F32, device=dev); rstd = torch.empty_like(mean)
     ops.ln_modulate_fwd(rows, y, None, None, (mod[:, :D], mod[:, D:], mod[:, :D], mod[:, D:], 2 * D), mean, rstd, D, N, 0, 1e-6)
     tok = m._lin(y, "final_layer.linear.weight", "final_layer.linear.bias")                                                         # [B N, pt ph pw C]
+    if tokens:
+        return tok.view(B, N, -1), (rows, mean, rstd, mod)
     out = tok.view(B, tt, th, tw, oc, pt, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, oc, tt * pt, th * ph, tw * pw)
     return out, (rows, mean, rstd, mod)
 
@@ -761,9 +829,9 @@ class _HYFinal(torch.autograd.Function):
     """FinalLayer + unpatchify with the gradient w.r.t. the trunk output only (its own weights are frozen)"""
 
     @staticmethod
-    def forward(ctx, xx, m, vec, N, dims):
-        out, saved = _final_forward(m, xx, vec, N, dims)
-        ctx.m, ctx.N, ctx.dims, ctx.saved, ctx.shape = m, N, dims, saved, xx.shape
+    def forward(ctx, xx, m, vec, N, dims, tokens=False):
+        out, saved = _final_forward(m, xx, vec, N, dims, tokens)
+        ctx.m, ctx.N, ctx.dims, ctx.saved, ctx.shape, ctx.tokens = m, N, dims, saved, xx.shape, tokens
         return out
 
     @staticmethod
@@ -773,7 +841,10 @@ class _HYFinal(torch.autograd.Function):
         D = m.hidden_size
         pt, ph, pw = m.patch_size
         oc = m.out_channels
-        dtok = dout.to(BF16).reshape(B, oc, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * N, oc * pt * ph * pw)
+        if ctx.tokens:
+            dtok = dout.to(BF16).reshape(B * N, oc * pt * ph * pw)
+        else:
+            dtok = dout.to(BF16).reshape(B, oc, tt, pt, th, ph, tw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * N, oc * pt * ph * pw)
         w = m._w("final_layer.linear.weight")                         # [n_out, D]
         n_out = w.shape[0]
         Kp = (n_out + 63) // 64 * 64
@@ -785,7 +856,7 @@ class _HYFinal(torch.autograd.Function):
         ops.ln_modulate_bwd(dy, rows, mean, rstd, None, (mod[:, D:], mod[:, D:], 2 * D), None, dx, D, N, 0)
         dxx = torch.zeros(ctx.shape, dtype=BF16, device=dout.device)
         dxx[:, :N] = dx.view(B, N, D)
-        return dxx, None, None, None, None
+        return dxx, None, None, None, None, None
 
 
 def rope_tables(sizes, rope_dim_list=(16, 56, 56), theta: float = 256.0):
@@ -838,16 +909,25 @@ class HunyuanVideoFlow(torch.nn.Module):
         t = (sigma * 1000.0).long()
         out = self.model(xt, t, text_states=prompt_embeds, text_mask=mask, text_states_2=pooled, freqs_cos=self._rope[key][0],
                          freqs_sin=self._rope[key][1], guidance=guidance, return_dict=False)
+        if self.model.sp_group is not None:
+            # sequence parallel: the model returned this rank's rows of the prediction as tokens; the mean squared error over ITS rows (the
+            # mean over the group's ranks is the loss of the step; a reducer that averages gradients over all ranks does the rest)
+            lo, Nl = self.model._sp_rows(out.shape[1] * torch.distributed.get_world_size(self.model.sp_group))
+            return _FlowLoss.apply(out, self.model.patchify(x0.float())[:, lo:lo + Nl].contiguous(), self.model.patchify(noise.float())[:, lo:lo + Nl].contiguous())
         return _FlowLoss.apply(out, x0.float(), noise.float())
 
     def training_step(self, batch, batch_idx=0):
         x0 = batch["latents"]
         B = x0.shape[0]
         idx = (torch.rand(B, device=x0.device) * self.sigmas.numel()).long().clamp_(max=self.sigmas.numel() - 1)
+        noise = torch.randn_like(x0, dtype=torch.float32)
+        group = self.model.sp_group
+        if group is not None:                       # one sample, one sigma, one noise for the ranks that share its rows (the batch is the caller's)
+            src = torch.distributed.get_global_rank(group, 0)
+            torch.distributed.broadcast(idx, src, group=group); torch.distributed.broadcast(noise, src, group=group)
         sigma = self.sigmas.to(x0.device)[idx]
         guidance = torch.full((B,), 1000.0, device=x0.device) if self.model.guidance_embed else None
-        return self.loss_from(x0, batch["prompt_embeds"], batch["prompt_attention_mask"], batch["pooled_prompt_embeds"], sigma,
-                              torch.randn_like(x0, dtype=torch.float32), guidance)
+        return self.loss_from(x0, batch["prompt_embeds"], batch["prompt_attention_mask"], batch["pooled_prompt_embeds"], sigma, noise, guidance)
 
 
 class _FlowLoss(torch.autograd.Function):

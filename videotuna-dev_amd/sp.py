@@ -29,6 +29,10 @@ import torch.distributed as dist
 
 
 def _a2a(x: torch.Tensor, group) -> torch.Tensor:
+    if x.is_cuda and dist.get_backend(group) == "gloo":          # rehearsal of several ranks on one card: gloo exchanges host memory
+        out = torch.empty(x.shape, dtype=x.dtype)
+        dist.all_to_all_single(out, x.cpu(), group=group)
+        return out.to(x.device)
     out = torch.empty_like(x)
     dist.all_to_all_single(out, x, group=group)
     return out
@@ -162,3 +166,78 @@ class _DeviceCore(torch.autograd.Function):
 
 def device_core(q, k, v, kv_len):
     return _DeviceCore.apply(q, k, v, None if kv_len is None else kv_len.to(torch.int32).contiguous())
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# The same exchange for the tape engine of hunyuan.py (no torch autograd): four explicit steps on the engine's joint buffers.
+#
+# Layout on a rank: joint rows of sample b are [its Li/P image rows ; the Lt text rows] (``Ljl = Li/P + Lt``), columns [q | k | v] of all
+# H heads.  The attention runs on ``joint2`` [B, Li + Lt, 3 * (H/P) * d]: every image row (ordered by source rank = global order) and the
+# text rows, this rank's H/P heads.
+#
+# Gradient convention here: PARTIAL SUMS.  The text stream is computed P times (once per rank, identical values); the exchange is
+# differentiated as the graph it really is -- rank r's copy of the text rows feeds the attention only through head slice r, and rank r's
+# attention output for the text rows is broadcast into every rank's copy.  So the backward of the all-gather is a sum over the ranks'
+# incoming gradients (then this rank's head slice), and the backward of the head slice is a zero-padded placement.  Text-row gradients
+# (and everything downstream of them, the modulation vector's gradient included) are then partial on each rank and their SUM over the group
+# is the gradient -- exactly how a data-parallel reducer treats ranks: with each rank back-propagating the mean loss of ITS image rows, the
+# group AVERAGE of every parameter gradient is the gradient of the mean loss over all rows.  No 1/P bookkeeping anywhere.
+# ----------------------------------------------------------------------------------------------------------------------------------------
+def _geom(group, H: int):
+    group = group if group is not None else dist.group.WORLD
+    P, r = dist.get_world_size(group), dist.get_rank(group)
+    if H % P:
+        raise ValueError(f"{H} heads do not split over {P} ranks")
+    return group, P, r, H // P
+
+
+def joint_to_heads(joint: torch.Tensor, B: int, Lil: int, Lt: int, H: int, d: int, group=None) -> torch.Tensor:
+    """joint [B * (Lil + Lt), 3 H d] (local rows, all heads) -> joint2 [B, P Lil + Lt, 3 (H/P) d]: ONE all-to-all for q, k and v together"""
+    group, P, r, h = _geom(group, H)
+    j5 = joint.view(B, Lil + Lt, 3, P, h * d)
+    send = j5[:, :Lil].permute(3, 0, 1, 2, 4).contiguous()                           # [dest rank = head chunk, B, Lil, 3, h d]
+    recv = _a2a(send, group)                                                         # [source rank = row chunk, B, Lil, 3, h d]
+    joint2 = torch.empty(B, P * Lil + Lt, 3 * h * d, dtype=joint.dtype, device=joint.device)
+    joint2[:, :P * Lil].view(B, P, Lil, 3, h * d).copy_(recv.permute(1, 0, 2, 3, 4))
+    joint2[:, P * Lil:].view(B, Lt, 3, h * d).copy_(j5[:, Lil:, :, r])
+    return joint2
+
+
+def heads_to_rows(o2: torch.Tensor, o3: torch.Tensor, B: int, Lil: int, Lt: int, H: int, d: int, group=None) -> None:
+    """o2 [B, P Lil + Lt, (H/P) d] (all rows, my heads) -> o3 [B, Lil + Lt, H d] view of the local output (rows may be strided)"""
+    group, P, r, h = _geom(group, H)
+    Li = P * Lil
+    send = o2[:, :Li].view(B, P, Lil, h * d).permute(1, 0, 2, 3).contiguous()         # [dest rank = row chunk, B, Lil, h d]
+    recv = _a2a(send, group)                                                         # [source rank = head chunk, B, Lil, h d]
+    o3[:, :Lil].copy_(recv.permute(1, 2, 0, 3).reshape(B, Lil, H * d))
+    txt = o2[:, Li:].contiguous()                                                    # [B, Lt, h d]: every rank's copy of the text rows needs all heads
+    parts = [torch.empty_like(txt) for _ in range(P)]
+    dist.all_gather(parts, txt, group=group)
+    o3[:, Lil:].copy_(torch.stack(parts, 2).reshape(B, Lt, H * d))
+
+
+def rows_grad_to_heads(g3: torch.Tensor, B: int, Lil: int, Lt: int, H: int, d: int, group=None) -> torch.Tensor:
+    """backward of heads_to_rows: g3 [B, Lil + Lt, H d] view (local rows; text rows PARTIAL) -> go2 [B, P Lil + Lt, (H/P) d]"""
+    group, P, r, h = _geom(group, H)
+    send = g3[:, :Lil].reshape(B, Lil, P, h * d).permute(2, 0, 1, 3).contiguous()     # [dest rank = head chunk, B, Lil, h d]
+    recv = _a2a(send, group)                                                         # [source rank = row chunk, B, Lil, h d]
+    go2 = torch.empty(B, P * Lil + Lt, h * d, dtype=g3.dtype, device=g3.device)
+    go2[:, :P * Lil].view(B, P, Lil, h * d).copy_(recv.permute(1, 0, 2, 3))
+    acc = torch.float32 if g3.dtype in (torch.bfloat16, torch.float16) else g3.dtype
+    gt = g3[:, Lil:].to(acc).contiguous()                                            # sum of the ranks' partial text gradients, in fp32
+    dist.all_reduce(gt, group=group)
+    go2[:, P * Lil:].copy_(gt.view(B, Lt, P, h * d)[:, :, r])
+    return go2
+
+
+def heads_grad_to_joint(dj2: torch.Tensor, B: int, Lil: int, Lt: int, H: int, d: int, group=None) -> torch.Tensor:
+    """backward of joint_to_heads: dj2 [B, P Lil + Lt, 3 (H/P) d] -> dj [B * (Lil + Lt), 3 H d] (text rows: this rank's heads, zeros elsewhere)"""
+    group, P, r, h = _geom(group, H)
+    send = dj2[:, :P * Lil].view(B, P, Lil, 3, h * d).permute(1, 0, 2, 3, 4).contiguous()   # [dest rank = row chunk, B, Lil, 3, h d]
+    recv = _a2a(send, group)                                                         # [source rank = head chunk, B, Lil, 3, h d]
+    dj = torch.empty(B * (Lil + Lt), 3 * H * d, dtype=dj2.dtype, device=dj2.device)
+    d5 = dj.view(B, Lil + Lt, 3, P, h * d)
+    d5[:, :Lil].copy_(recv.permute(1, 2, 3, 0, 4))
+    d5[:, Lil:].zero_()
+    d5[:, Lil:, :, r].copy_(dj2[:, P * Lil:].view(B, Lt, 3, h * d))
+    return dj

@@ -267,39 +267,56 @@ def bench_hunyuan(args):
     from vt355.ddp import init_from_env
     from vt355.hunyuan import HunyuanBlocks, flow_matching_loss
     from vt355.optim import FusedAdamW
+    import torch.distributed as dist
+    from vt355.ddp import FlatGradReducer
     rank, local, world = init_from_env(os.environ.get("VT_DDP_BACKEND"))
-    assert world == args.gpus == 1, "the HunyuanVideo line is single-GPU"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("VT_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    lora = args.mode == "lora" and args.layers == 30 and os.environ.get("VT_HY_FULLFT") is None
+    lora = args.mode == "lora" and os.environ.get("VT_HY_FULLFT") is None
     if lora:
-        nd, ns = 20, 40               # the whole trunk: frozen block weights (25.7 GB bf16) + rank-4 adapters, as the shipped recipe trains
+        # the whole trunk: frozen block weights (25.7 GB bf16) + rank-4 adapters, as the shipped recipe trains (--layers: debug depth)
+        nd, ns = (20, 40) if args.layers == 30 else (max(1, args.layers // 3), max(1, args.layers - args.layers // 3))
     else:
+        assert world == 1, "the full-FT block-trunk line is single-GPU"
         nd, ns = (4, 8) if args.layers == 30 else (max(1, args.layers // 3), max(1, args.layers - args.layers // 3))
-    D, H, Li, Lt = 3072, 24, 10200, 256
+    lT, lH, lW = (int(v) for v in args.latent.split(","))
+    D, H, Li, Lt = 3072, 24, lT * (lH // 2) * (lW // 2), 256
+    sp_deg = args.sp
+    assert world % sp_deg == 0 and H % sp_deg == 0 and Li % sp_deg == 0, (world, sp_deg, Li)
+    n_dp, dp_idx = world // sp_deg, rank // sp_deg
     B = args.micro_batch if args.micro_batch is not None else 1
-    g = torch.Generator(device=dev).manual_seed(20230211)
+    g = torch.Generator(device=dev).manual_seed(20230211 + dp_idx)          # the ranks of a sequence-parallel group see the same batch
     tv = torch.tensor([Lt - 37 * (b % 5) for b in range(B)], device=dev)
     losses = []
     ops.profile_reset(True)
     if lora:
         # the WHOLE denoiser (patch embed, token refiner, modulation vector, 20 + 40 blocks, final layer) through the workflow's training_step:
-        # latents [B, 16, 5, 68, 120] = 544x960x17f after the 4x8x8 VAE -> 10 200 tokens, LLM embeddings [B, 256, 4096] (ragged), CLIP pooled [B, 768]
+        # latents [B, 16, T, H, W] (default 5 x 68 x 120 = 544x960x17f after the 4x8x8 VAE -> 10 200 tokens; 33,90,160 = 720p x 129f -> 118 800),
+        # LLM embeddings [B, 256, 4096] (ragged), CLIP pooled [B, 768]
         from vt355.hunyuan import HYVideoDiffusionTransformer, HunyuanVideoFlow
         model = HYVideoDiffusionTransformer(mm_double_blocks_depth=nd, mm_single_blocks_depth=ns, lora_rank=4).to(dev).init_weights(11)
         model.lora.init_weights(12, zero_b=False)
+        if sp_deg > 1:        # every rank creates every group; image tokens of a sample split over the sp_deg ranks of its group (vt355.sp)
+            groups = [dist.new_group(list(range(i * sp_deg, (i + 1) * sp_deg))) for i in range(n_dp)]
+            model.set_sequence_parallel(groups[dp_idx])
+            torch.manual_seed(977 + rank)      # training_step's own draws (sigma, noise): not the batch generator's stream
         flow = HunyuanVideoFlow(model=model, learning_rate=1e-5).to(dev)
         opt = flow.configure_optimizers()
+        red = FlatGradReducer(model.lora.train_state.grad)                  # adapters: ONE all-reduce over all ranks (data and sequence parallel alike)
         mask = (torch.arange(Lt, device=dev)[None, :] < tv[:, None]).long()
 
         def step():
-            batch = {"latents": torch.randn(B, 16, 5, 68, 120, device=dev, generator=g),
+            batch = {"latents": torch.randn(B, 16, lT, lH, lW, device=dev, generator=g),
                      "prompt_embeds": torch.randn(B, Lt, 4096, device=dev, generator=g).to(torch.bfloat16), "prompt_attention_mask": mask,
                      "pooled_prompt_embeds": torch.randn(B, 768, device=dev, generator=g).to(torch.bfloat16)}
             loss = flow.training_step(batch)
             loss.backward()
             losses.append(loss.detach())
-            opt.step()
+            red.reduce()
+            opt.step(grad_scale=red.grad_scale)
     else:
         model = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=nd, mm_single_blocks_depth=ns).to(dev).init_weights(11)
         ts = model.enable_training()
@@ -319,16 +336,29 @@ def bench_hunyuan(args):
             losses.append(loss.detach())
             opt.step()
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    barrier()
     ops.profile_reset(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     prof, work = ops.profile_collect(), ops.profile_work()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    if rank != 0:
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
     kern = {k: {"avg_ms": ms, "launches": n, **({"tflops_algorithmic": work[k] / (ms * n) / 1e9} if work.get(k) else {})} for k, (ms, n) in prof.items()}
     S = Li + Lt
     # per block forward: linears + attention 4 S^2 d; double: img+txt streams (qkv, proj, fc1, fc2 = 24 S d^2 over both streams); single: linear1 + linear2
@@ -336,25 +366,28 @@ def bench_hunyuan(args):
     fwd_single = 2.0 * S * D * (3 * D + 4 * D) + 2.0 * S * (D + 4 * D) * D + 4.0 * S * S * D
     att = 4.0 * S * S * D
     if lora:    # forward + backward without the frozen weights' dW: linears 2x, attention 3x
-        step_tf = B * (nd * (2.0 * (fwd_double - att) + 3.0 * att) + ns * (2.0 * (fwd_single - att) + 3.0 * att)) / 1e12
+        step_tf = B * n_dp * (nd * (2.0 * (fwd_double - att) + 3.0 * att) + ns * (2.0 * (fwd_single - att) + 3.0 * att)) / 1e12
     else:
         step_tf = 3.0 * B * (nd * fwd_double + ns * fwd_single) / 1e12
     lv = [float(x) for x in torch.stack(losses[-args.steps:]).cpu()]
-    print(json.dumps({"metric": ("finetune samples/sec, HunyuanVideo-T2V denoiser (whole HYVideoDiffusionTransformer, 20 + 40 blocks) 544x960x17f LoRA r=4 bf16" if lora else
+    size = f"latents 16x{lT}x{lH}x{lW}"
+    print(json.dumps({"metric": (f"finetune samples/sec, HunyuanVideo-T2V denoiser (whole HYVideoDiffusionTransformer, {nd} + {ns} blocks) {size} LoRA r=4 bf16" if lora else
                                  "finetune samples/sec, HunyuanVideo block trunk (%d double + %d single of 20 + 40) 544x960x17f full-FT bf16" % (nd, ns)),
-                      "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "value": B * n_dp * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                       "data": "synthetic",
-                      "config": {"workload": ("HunyuanVideo-T2V denoiser through HunyuanVideoFlow.training_step (configs[4] family at the shipped recipe's 544x960x17f, "
-                                              "1 GPU, NOT the headline config): patch embed + token refiner + " if lora else
+                      "config": {"workload": ("HunyuanVideo-T2V denoiser through HunyuanVideoFlow.training_step (configs[4] family, " + size + ", "
+                                              "NOT the headline config): patch embed + token refiner + " if lora else
                                               "HunyuanVideo MMDoubleStreamBlock / MMSingleStreamBlock trunk (configs[4] family, NOT the headline config and "
                                               "NOT the whole model): ") + f"{nd} double + {ns} single blocks, image tokens {Li} + text {Lt} (valid {tv.tolist()}), "
                                              "d 3072, 24 x 128, " + ("block weights frozen, rank-4 adapters on the image stream's q / k / v / out projections trained (configs/007 recipe), "
                                                                   if lora else "all block weights trained, ") + "flow-matching loss",
-                                 "mode": "lora" if lora else "fullft",
+                                 "mode": "lora" if lora else "fullft", "parallelism": f"dp{n_dp} x sp{sp_deg} (Ulysses)" if sp_deg > 1 else f"dp{n_dp}",
                                  "micro_batch": B, "double_blocks": nd, "single_blocks": ns, "weights": "seeded random init"},
                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1), "step_tflops_algorithmic": step_tf * args.steps / elapsed,
                       "kernels": kern, "loss_first": lv[0], "loss_last": lv[-1]}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def main():
@@ -379,6 +412,8 @@ def main():
                          "(cogvideo_pl.py:792-813); default: pre-encoded latents")
     ap.add_argument("--mode", choices=["lora", "fullft"], default="lora",
                     help="lora = BASELINE configs[1] (the headline metric); fullft = configs[2], every weight trainable")
+    ap.add_argument("--sp", type=int, default=1, help="--model hunyuan: Ulysses sequence-parallel degree (ranks per sample); --gpus / --sp samples run data parallel")
+    ap.add_argument("--latent", default="5,68,120", help="--model hunyuan: latent T,H,W (5,68,120 = the shipped 544x960x17f recipe; 33,90,160 = 720p x 129 frames)")
     ap.add_argument("--encoder-cache", type=int, default=0, metavar="N",
                     help="with --vae-encoder / --text-encoder: the batches cycle through a synthetic dataset of N samples and the frozen encoders' "
                          "outputs are kept per sample (vt355.prefetch.EncodingCache: prompt embeddings by caption, latent MOMENTS by index, the "

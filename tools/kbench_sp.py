@@ -33,7 +33,7 @@ print(f"forward done: {f:.1f} ms", flush=True)
 g = t(lambda: ops.attn128_bwd(q, k, v, o, do, lse, dj[:, :, :c], dj[:, :, c:2 * c], dj[:, :, 2 * c:], h, scale, kv_len=kv_len))
 fl = 4.0 * S * S * c
 print(f"attn128 at S = {S} (720p x 129 frames), {h} of {H} heads ({P}-way Ulysses): fwd {f:.1f} ms = {fl / f / 1e9:.0f} TFLOP/s; "
-      f"two-pass bwd {g:.1f} ms = {2.5 * fl / g / 1e9:.0f} TFLOP/s algorithmic; x 60 blocks = {(f + g) * 60 / 1e3:.1f} s of attention per step and rank "
+      f"two-pass bwd {g:.1f} ms = {2.0 * fl / g / 1e9:.0f} TFLOP/s algorithmic (8 S^2 d h: dP, dV, dK, dQ; the recomputed S is not counted); x 60 blocks = {(f + g) * 60 / 1e3:.1f} s of attention per step and rank "
       f"(unsharded on one card: {P}x the heads = {(f + g) * 60 * P / 1e3:.0f} s)")
 rows = torch.randint(0, S, (64,), device=dev)
 worst = 0.0

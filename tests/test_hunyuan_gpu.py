@@ -458,3 +458,59 @@ def test_hunyuan_flow_training_step(dev):
                 text_states_2=batch["pooled_prompt_embeds"], freqs_cos=cos, freqs_sin=sin, return_dict=False)
         want = ((out.float() - (noise - batch["latents"])) ** 2).mean()
     assert abs(l2.item() - want.item()) < 1e-4 * want.item()
+
+
+def test_full_width_lora_blocks_train_step(dev):
+    """The model's real width -- hidden 3072, 24 heads x 128, MLP 12288 -- one double + one single block in the shipped recipe's LoRA mode (rank 4,
+    frozen block weights), 4 x 16 x 16 = 1024 image tokens + 64 text tokens (valid 64 / 40), B = 2: forward, input gradients and every adapter
+    gradient vs the fp32 oracle on the effective weights.  The tiny-model tests pin the composition; this one exercises the GEMM tilings, the
+    K-extended LoRA operands and the attention at the shapes the benchmark runs."""
+    import hunyuan_oracle as HO
+    from vt355.hunyuan import HunyuanBlocks, rope_tables
+    D, H, r = 3072, 24, 4
+    B, Li, Lt = 2, 1024, 64
+    m = HunyuanBlocks(hidden_size=D, heads_num=H, mm_double_blocks_depth=1, mm_single_blocks_depth=1, lora_rank=r, lora_alpha=4.0)
+    P = {**HO.init(HO.double_block_shapes(D, H, pre="double_blocks.0."), 1), **HO.init(HO.single_block_shapes(D, H, pre="single_blocks.0."), 2)}
+    m.load_state_dict(P, strict=False)
+    m.lora.init_weights(5, zero_b=False)
+    m.to(dev)
+    ts = m.enable_lora_training()
+    g = torch.Generator().manual_seed(31)
+    img, txt = (torch.randn(B, Li, D, generator=g) * 0.5).to(BF), (torch.randn(B, Lt, D, generator=g) * 0.5).to(BF)
+    vec = torch.randn(B, D, generator=g).to(BF)
+    tv = torch.tensor([64, 40])
+    cos, sin = rope_tables((4, 16, 16))
+    gx = (torch.randn(B, Li + Lt, D, generator=g) * 0.1).to(BF)
+    gx[1, Li + 40:] = 0
+    xi, xt, xv = [t.to(dev).requires_grad_(True) for t in (img, txt, vec)]
+    out = m(xi, xt, xv, tv.to(dev), (cos.to(dev), sin.to(dev)))
+    out.backward(gx.to(dev))
+    torch.cuda.synchronize()
+    base = {k: v.detach().float().cpu() for k, v in m.named_parameters() if not k.startswith("lora.")}
+    ad = {k[5:]: v.detach().float().cpu().requires_grad_(True) for k, v in m.named_parameters() if k.startswith("lora.")}
+    s = m.lora.scaling
+    Pe = dict(base)
+    for mod, tags in m.lora.sites.items():
+        w = base[mod + ".weight"].clone()
+        for j, t in enumerate(tags):
+            dot = "." + t if t else ""
+            w[j * D:(j + 1) * D] = w[j * D:(j + 1) * D] + s * ad[f"{mod}.lora_B{dot}.weight"] @ ad[f"{mod}.lora_A{dot}.weight"]
+        Pe[mod + ".weight"] = w
+    ri, rt, rv = [t.float().requires_grad_(True) for t in (img, txt, vec)]
+    io, to = HO.double_block(ri, rt, rv, Pe, "double_blocks.0.", H, tv, cos, sin)
+    xo = HO.single_block(torch.cat([io, to], 1), rv, Pe, "single_blocks.0.", H, Lt, tv, cos, sin)
+    (xo * gx.float()).sum().backward()
+    vm = torch.ones(B, Li + Lt, 1); vm[1, Li + 40:] = 0
+    e_out = _rel(out.float().cpu() * vm, xo * vm)
+    e_img, e_vec = _rel(xi.grad, ri.grad), _rel(xv.grad, rv.grad)
+    e_txt = _rel(xt.grad.float().cpu() * vm[:, Li:], rt.grad * vm[:, Li:])
+    worst = 0.0
+    for n in m.lora.shapes:
+        gd = m.lora._view(ts.grad, n).detach().float().cpu()
+        gr = ad[n].grad
+        e = ((gd - gr).norm() / gr.norm().clamp_min(1e-20)).item()
+        cosine = torch.nn.functional.cosine_similarity(gd.flatten(), gr.flatten(), dim=0).item()
+        worst = max(worst, e)
+        assert cosine > 0.98 and e < 0.2, (n, e, cosine)
+    print(f"[hunyuan full width] fwd rel-L2 {e_out:.3e}; dimg {e_img:.3e} dtxt {e_txt:.3e} dvec {e_vec:.3e}; adapter grads worst rel-L2 {worst:.3e}")
+    assert e_out < 1e-2 and e_img < 3e-2 and e_txt < 3e-2 and e_vec < 3e-2

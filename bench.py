@@ -675,12 +675,19 @@ def main():
         alg = {"attn_bwd": 8.0 * S * S * d * B, "attn_fwd": 4.0 * S * S * d * B}     # algorithmic FLOPs per launch
         work = ops.profile_work()
         kern = {}
+        hbm_kernels = {"ln_modulate_fwd": "ln_modulate_fwd_kernel (LayerNorm + adaLN shift / scale)", "ln_modulate_bwd": "ln_modulate_bwd_kernel",
+                       "qk_layernorm_fwd": "qk_layernorm_fwd_kernel (per-head q / k LayerNorm)", "qk_layernorm_bwd": "qk_layernorm_bwd_kernel",
+                       "adamw": "adamw_kernel (fp32 master, moments, bf16 copy)"}
         for name, (ms, n) in prof.items():
             kern[name] = {"avg_ms": ms, "launches": n}
             if name in alg:
                 kern[name]["tflops_algorithmic"] = alg[name] / ms / 1e9
+            elif name in hbm_kernels:             # memory-bound kernels: the recorded work is algorithmic HBM bytes (SURVEY 8(d) ii)
+                kern[name]["gb_per_s_algorithmic"] = work[name] / (ms * n) / 1e6
             elif name in work:
                 kern[name]["tflops_algorithmic"] = work[name] / (ms * n) / 1e9
+        hbm_lines = [{"bound": "hbm", "kernel": hbm_kernels[name], "achieved": kern[name]["gb_per_s_algorithmic"], "peak": 8000.0, "unit": "GB/s",
+                      "frac": kern[name]["gb_per_s_algorithmic"] / 8000.0} for name in hbm_kernels if name in kern and "gb_per_s_algorithmic" in kern[name]]
         dom = "attn_bwd"
         ach = kern[dom]["tflops_algorithmic"] if dom in kern else None
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the figure comes from
@@ -739,7 +746,7 @@ def main():
                 {"bound": "mfma", "kernel": "attn_fwd_hd64_kernel", "achieved": kern.get("attn_fwd", {}).get("tflops_algorithmic"), "peak": 2500.0,
                  "unit": "TFLOP/s", "frac": (kern["attn_fwd"]["tflops_algorithmic"] / 2500.0) if "attn_fwd" in kern else None},
                 {"bound": "mfma", "kernel": "gemm_tn_* (every Linear with >= 4096 rows, forward and dX)", "achieved": kern.get("gemm", {}).get("tflops_algorithmic"),
-                 "peak": 2500.0, "unit": "TFLOP/s", "frac": (kern["gemm"]["tflops_algorithmic"] / 2500.0) if kern.get("gemm", {}).get("tflops_algorithmic") else None}],
+                 "peak": 2500.0, "unit": "TFLOP/s", "frac": (kern["gemm"]["tflops_algorithmic"] / 2500.0) if kern.get("gemm", {}).get("tflops_algorithmic") else None}] + hbm_lines,
             "kernels": kern,
             "ddp": {"backend": (dist.get_backend() if world > 1 else None), "world_size_seen": (dist.get_world_size() if world > 1 else 1),
                     "allreduce_bytes_per_step": (int(st.grad.numel() * (2 if (args.mode == "fullft" and args.allreduce_dtype == "bf16") else 4)) if world > 1 else 0),

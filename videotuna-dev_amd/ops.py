@@ -66,6 +66,11 @@ class _timed:
             _PROFILE["events"].setdefault(self.name, []).append((self.a, b))
 
 
+def _timed_hbm(name, rows, nbytes):
+    """memory-bound kernels at the benchmark's row counts: work = algorithmic HBM bytes (bench.py turns it into GB/s)"""
+    return _timed(name, nbytes) if (_PROFILE["on"] and rows >= 4096) else _NOTIME
+
+
 class _NoTime:
     def __enter__(self):
         return self
@@ -439,9 +444,10 @@ def ln_modulate_fwd(x, y, gamma, beta, mod, mean, rstd, D: int, S: int, St: int,
     _req(x, BF16, "x", 2); _req(y, BF16, "y", 2)
     m = (None, None, None, None, 0) if mod is None else mod
     lib = load_library()
-    check(lib.vt_ln_modulate_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _p(gamma), _p(beta),
-                                 _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]), m[4], _p(mean), _p(rstd),
-                                 x.shape[0], D, S, St, eps, _stream()), "vt_ln_modulate_fwd")
+    with _timed_hbm("ln_modulate_fwd", x.shape[0], 4.0 * x.shape[0] * D):           # x read, y written, bf16
+        check(lib.vt_ln_modulate_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _p(gamma), _p(beta),
+                                     _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]), m[4], _p(mean), _p(rstd),
+                                     x.shape[0], D, S, St, eps, _stream()), "vt_ln_modulate_fwd")
 
 
 def ln_modulate_bwd(dy, x, mean, rstd, gamma, scales, dres, dx, D: int, S: int, St: int):
@@ -449,28 +455,31 @@ def ln_modulate_bwd(dy, x, mean, rstd, gamma, scales, dres, dx, D: int, S: int, 
     _req(dy, BF16, "dy", 2); _req(x, BF16, "x", 2); _req(dx, BF16, "dx", 2)
     sc = (None, None, 0) if scales is None else scales
     lib = load_library()
-    check(lib.vt_ln_modulate_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
-                                 _p(gamma), _p(sc[0]), _p(sc[1]), sc[2], _p(dres), 0 if dres is None else dres.stride(0),
-                                 dx.data_ptr(), dx.stride(0), x.shape[0], D, S, St, _stream()), "vt_ln_modulate_bwd")
+    with _timed_hbm("ln_modulate_bwd", x.shape[0], (6.0 if dres is None else 8.0) * x.shape[0] * D):   # dy, x (, residual gradient) read, dx written
+        check(lib.vt_ln_modulate_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                     _p(gamma), _p(sc[0]), _p(sc[1]), sc[2], _p(dres), 0 if dres is None else dres.stride(0),
+                                     dx.data_ptr(), dx.stride(0), x.shape[0], D, S, St, _stream()), "vt_ln_modulate_bwd")
 
 
 def qk_layernorm_fwd(qkv, out, gq, bq, gk, bk, mean, rstd, H: int, eps: float, q_scale: float = 1.0, rope=None):
     _req(qkv, BF16, "qkv", 2); _req(out, BF16, "out", 2)
     lib = load_library()
     rc, rsn, S, St = _rope_args(rope, qkv.shape[0])
-    check(lib.vt_qk_layernorm_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), bq.data_ptr(),
-                                  gk.data_ptr(), bk.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.shape[0], H, eps,
-                                  q_scale, rc, rsn, S, St, _stream()), "vt_qk_layernorm_fwd")
+    with _timed_hbm("qk_layernorm_fwd", qkv.shape[0], 8.0 * qkv.shape[0] * H * 64):   # q, k thirds read, q_hat | k_hat written
+        check(lib.vt_qk_layernorm_fwd(qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), gq.data_ptr(), bq.data_ptr(),
+                                      gk.data_ptr(), bk.data_ptr(), mean.data_ptr(), rstd.data_ptr(), qkv.shape[0], H, eps,
+                                      q_scale, rc, rsn, S, St, _stream()), "vt_qk_layernorm_fwd")
 
 
 def qk_layernorm_bwd(dq_hat_f32, dk_hat, qkv, mean, rstd, gq, gk, dqkv, H: int, rope=None):
     _req(dq_hat_f32, torch.float32, "dq_hat", 2); _req(dk_hat, BF16, "dk_hat", 2)
     lib = load_library()
     rc, rsn, S, St = _rope_args(rope, qkv.shape[0])
-    check(lib.vt_qk_layernorm_bwd(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
-                                  qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), gq.data_ptr(), gk.data_ptr(),
-                                  dqkv.data_ptr(), dqkv.stride(0), qkv.shape[0], H, rc, rsn, S, St, _stream()),
-          "vt_qk_layernorm_bwd")
+    with _timed_hbm("qk_layernorm_bwd", qkv.shape[0], 14.0 * qkv.shape[0] * H * 64):  # fp32 dq_hat, bf16 dk_hat, q, k read; dq, dk written
+        check(lib.vt_qk_layernorm_bwd(dq_hat_f32.data_ptr(), dq_hat_f32.stride(0), dk_hat.data_ptr(), dk_hat.stride(0),
+                                      qkv.data_ptr(), qkv.stride(0), mean.data_ptr(), rstd.data_ptr(), gq.data_ptr(), gk.data_ptr(),
+                                      dqkv.data_ptr(), dqkv.stride(0), qkv.shape[0], H, rc, rsn, S, St, _stream()),
+              "vt_qk_layernorm_bwd")
 
 
 def gate_mul(x, y, g_txt, g_vid, bstride: int, D: int, S: int, St: int):
@@ -538,8 +547,9 @@ def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step: int, grad_scale: 
         _req(t, torch.float32, n)
     if guard is not None:
         _req(guard, torch.int32, "guard")
-    check(load_library().vt_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(),
-                                  lr, beta1, beta2, eps, wd, step, grad_scale, _p(guard), _stream()), "vt_adamw")
+    with _timed_hbm("adamw", p.numel(), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * p.numel()):   # p, g, m, v read; p, m, v (+ bf16 copy) written
+        check(load_library().vt_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(p_bf16), p.numel(),
+                                      lr, beta1, beta2, eps, wd, step, grad_scale, _p(guard), _stream()), "vt_adamw")
 
 
 def lora_down(x, a, R: int, t_out, K: int, zero_cols: int = 48):

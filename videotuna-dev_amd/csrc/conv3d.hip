@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_cl_kernel(Conv3dParams cp) {
 // v_mfma_f32_32x32x16_bf16, waves 4..7 only issue LDS-DMA two K-tiles ahead in a three-stage ring, persistent over the output
 // tiles).  The address generation of the implicit GEMM -- decode of the output positions, per-tap validity and offsets -- runs in
 // the loader waves, which have nothing else to do, so the multipliers see an ordinary GEMM.
+#ifndef CP_MFMA16
+#define CP_MFMA16 1        // 16x16x32 MFMA body in the producer / consumer kernel (see gemm_big_bf16.hip GB_MFMA16)
+#endif
 #define CP_BM 256
 #define CP_STAGE 49152      // A 32 KiB | W 16 KiB
 #define CP_NS 3
@@ -295,10 +298,57 @@ __global__ __launch_bounds__(512, 1) void conv3d_pc_kernel(Conv3dParams cp) {
     // =================================== multiplier waves (an ordinary GEMM from here on) ===================================
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 31, fh = lane >> 5, fx = (fr >> 1) & 7;
+    const int fr16 = lane & 15, fq = lane >> 4, fx16 = (fr16 >> 1) & 7;
     const int er = tid >> 5, ec = (tid & 31) * 4;
     int g = 0;
     for (int tile = slot; tile < ntiles; tile += gridDim.x) {
         const int row0 = (tile / nbn) * CP_BM, col0 = (tile % nbn) * CV_BN;
+#if CP_MFMA16
+        // v_mfma_f32_16x16x32_bf16 body (gemm_pc_bf16.hip): 8 x 4 tiles of 16 x 16 per wave, two 32-deep k-steps per K-tile, reads one sub-step ahead
+        f32x4 acc16[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            cp_barrier();                    // (A) the loaders have landed stage g % 3
+            const char* As = smem + (g % CP_NS) * CP_STAGE + (wm * 128 + fr16) * 128;
+            const char* Ws = smem + (g % CP_NS) * CP_STAGE + 32768 + (wn * 64 + fr16) * 128;
+            bf16x8 af[2][8], wf[2][4];
+            auto frags_w = [&](int ks) {
+                const int coff = (((ks * 4 + fq) ^ fx16) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wf[ks][t] = *(const bf16x8*)(Ws + t * 2048 + coff);
+            };
+            auto frags_a = [&](int ks, int h) {
+                const int coff = (((ks * 4 + fq) ^ fx16) << 4);
+#pragma unroll
+                for (int t = h * 4; t < (h + 1) * 4; ++t) af[ks][t] = *(const bf16x8*)(As + t * 2048 + coff);
+            };
+            auto mm = [&](int ks, int h) {
+#pragma unroll
+                for (int tm = h * 4; tm < (h + 1) * 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc16[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], af[ks][tm], acc16[tn][tm], 0, 0, 0);
+            };
+            frags_w(0); frags_a(0, 0);
+            frags_a(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_w(1); frags_a(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_a(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         f32x16 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -331,6 +381,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_pc_kernel(Conv3dParams cp) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         // ---------------- epilogue: eight 32-row slabs through the stage that was just consumed (17 barriers) ----------------
         float* Cs = (float*)(smem + ((g - 1) % CP_NS) * CP_STAGE);
         const int n = col0 + ec;
@@ -343,6 +394,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_pc_kernel(Conv3dParams cp) {
 #pragma unroll
         for (int slab = 0; slab < 8; ++slab) {
             if (wm == (slab >> 2)) {
+#if CP_MFMA16
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        *(f32x4*)(Cs + (t2 * 16 + fr16) * CV_CS_LD + wn * 64 + tn * 16 + 4 * fq) = acc16[tn][(slab & 3) * 2 + t2];
+#else
                 const int tm = slab & 3;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
@@ -350,6 +408,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_pc_kernel(Conv3dParams cp) {
                     for (int q = 0; q < 4; ++q)
                         *(f32x4*)(Cs + fr * CV_CS_LD + wn * 64 + tn * 32 + 8 * q + 4 * fh) =
                             (f32x4){acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+#endif
             }
             cp_barrier();
 #pragma unroll

@@ -27,6 +27,12 @@
 #define GP_BM 256           // rows of the standard tile; the BM = 128 instantiation (four-stage ring) serves few-row GEMMs
 #define GP_BN 128
 #define GP_BK 64
+#ifndef GP_MFMA16
+#define GP_MFMA16 1         // 1: v_mfma_f32_16x16x32_bf16 (16-row fragments, two 32-deep k-steps per K-tile) instead of v_mfma_f32_32x32x16_bf16:
+#endif                      // same LDS image and bytes per flop; the chip holds a higher clock on this shape under load (gemm_big_bf16.hip)
+#ifndef GP_SUB
+#define GP_SUB 1           // 1: fragment reads issued one sub-step (k-step x half of the A tiles) ahead: +1 % on the 72 008-row shapes; 0: one k-step ahead
+#endif
 #define GP_CS_LD 132        // fp32 row stride of the epilogue staging slab (32 rows x 132 floats = 16.5 KiB)
 template <int BM> struct GpCfg {
     static constexpr int STAGE = BM * 128 + 16384;          // A (BM rows x 128 B) | W 16 KiB
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
     const int fr = lane & 31;             // row inside a 32-row fragment
     const int fh = lane >> 5;             // which 8-element half of a 16-deep k-step
     const int fx = (fr >> 1) & 7;         // swz(row)
+    const int fr16 = lane & 15, fq = lane >> 4, fx16 = (fr16 >> 1) & 7;   // 16-row fragments (GP_MFMA16)
     const int er = tid >> 5;              // epilogue (256 threads): 0..7, row inside an 8-row pass
     const int ec = (tid & 31) * 4;        // first of this thread's 4 columns
     int g = 0;
@@ -154,6 +161,80 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
         const GpTile cur = gp_tile<BM>(p, tile % ntiles_mn, nbm, nbn);
         // acc[tn][tm] = D[n][m] of (W-fragment, A-fragment): lane holds m = lane & 31 and, in register r, column
         // n = 8 (r>>2) + 4 (lane>>5) + (r&3): four consecutive output columns per register quad
+#if GP_MFMA16
+        // acc16[tn][tm] = D[n][m] of a 16 x 16 tile: lane holds m = lane & 15 and the four consecutive columns n = 4 (lane >> 4) + r
+        constexpr int TM16 = 2 * TM;
+        f32x4 acc16[4][TM16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TM16; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            gp_barrier();                    // (A) the loaders have landed stage g % 3
+            const char* As = smem + (g % GP_NS) * GP_STAGE + (wm * (BM / 2) + fr16) * 128;
+            const char* Ws = smem + (g % GP_NS) * GP_STAGE + BM * 128 + (wn * 64 + fr16) * 128;
+            bf16x8 af[2][TM16], wf[2][4];    // fragments of k-step ks in [ks]: the second set loads under the first set's MFMAs
+#if GP_SUB
+            // four sub-steps (k-step, half of the A tiles): the reads of a sub-step are issued one sub-step ahead, so only the first 4 + TM16/2
+            // reads of a K-tile are exposed behind the barrier
+            constexpr int HT = TM16 / 2;
+            auto frags_w = [&](int ks) {
+                const int coff = (((ks * 4 + fq) ^ fx16) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wf[ks][t] = *(const bf16x8*)(Ws + t * 2048 + coff);
+            };
+            auto frags_a = [&](int ks, int h) {
+                const int coff = (((ks * 4 + fq) ^ fx16) << 4);
+#pragma unroll
+                for (int t = h * HT; t < (h + 1) * HT; ++t) af[ks][t] = *(const bf16x8*)(As + t * 2048 + coff);
+            };
+            auto mm = [&](int ks, int h) {
+#pragma unroll
+                for (int tm = h * HT; tm < (h + 1) * HT; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc16[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], af[ks][tm], acc16[tn][tm], 0, 0, 0);
+            };
+            frags_w(0); frags_a(0, 0);
+            frags_a(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_w(1); frags_a(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_a(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+            auto frags = [&](int ks) {
+                const int coff = (((ks * 4 + fq) ^ fx16) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wf[ks][t] = *(const bf16x8*)(Ws + t * 2048 + coff);
+#pragma unroll
+                for (int t = 0; t < TM16; ++t) af[ks][t] = *(const bf16x8*)(As + t * 2048 + coff);
+            };
+            frags(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 0) frags(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM16; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc16[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], af[ks][tm], acc16[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+#else
         f32x16 acc[2][TM];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -189,6 +270,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         // ---------------- epilogue: eight 32-row slabs through the stage that was just consumed (17 barriers) ----------------
         float* Cs = (float*)(smem + ((g - 1) % GP_NS) * GP_STAGE);
         const int n = cur.col0 + ec;
@@ -215,6 +297,13 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
 #pragma unroll
         for (int slab = 0; slab < Cfg::SLABS; ++slab) {
             if (wm == slab / TM) {
+#if GP_MFMA16
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        *(f32x4*)(Cs + (t2 * 16 + fr16) * GP_CS_LD + wn * 64 + tn * 16 + 4 * fq) = acc16[tn][(slab % TM) * 2 + t2];
+#else
                 const int tm = slab % TM;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
@@ -224,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void GEMM_PC_KERNEL(GemmParams p) {
                         *(f32x4*)(Cs + fr * GP_CS_LD + nl) =
                             (f32x4){acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
                     }
+#endif
             }
             gp_barrier();
             if (slab < Cfg::SLABS - 1) aux_fetch(slab + 1, auxn);

@@ -101,6 +101,13 @@
 #ifndef VT_DMA
 #define VT_DMA (VT_PF && VT_W8 && !VT_DQ16)   // 1 = waves 4..7 stage the Q / dO tiles by LDS-DMA straight into the buffer the barrier before last freed (no
 #endif                                        // staging registers, no ds_write of the tile; waves 0..3, which carry the dQ phase, stage nothing)
+#ifndef VT_M16
+#define VT_M16 (VT_DMA && !VT_STAMP && !VT_STATMFMA && !PF_R0 && !VT_DMA_LATE && !VT_ABL)      // 1 (eight-wave body with VT_PF + VT_DMA only; shipped) = the four products of the S phase (S, dP, dV, dK) are issued as
+#endif                // v_mfma_f32_16x16x32_bf16 on 16 x 16 tiles instead of v_mfma_f32_32x32x16_bf16: same cycles per flop, but the chip holds a
+                      // higher clock on that shape under load (gemm_big_bf16.hip GB_MFMA16).  The Q / dO tile image then uses the swizzle
+                      // row & 6 (conflict-free for the 16-row ds_read_b128 fragments AND the transposed reads of a 16 x 16 x 32 operand);
+                      // the dS image keeps its format, so the dQ phase is untouched.  Same box, B=1: 6.58-6.77 against 6.90-6.95 ms (-4.7 %).
+                      // The instrumented / ablation builds (VT_STAMP, VT_STATMFMA, VT_ABL, PF_R0, VT_DMA_LATE) exist for the 32 x 32 body only: -DVT_M16=0.
 #ifndef VT_DMA_LATE
 #define VT_DMA_LATE 0  // 1 = waves 4..7 issue their staging pieces inside the S phase instead of right behind the barrier: measured slower (13.14 vs 12.83 ms, B=2)
 #endif
@@ -233,6 +240,22 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         *(u32x4*)(smem + KIMG + swz_off(key, c)) = v;
     }
     // ---- K / V fragments of this wave's 32 keys, resident for the whole key block ----
+#if VT_M16
+    // B operands of S = Q K^T and dP = dO V^T on 16 x 16 x 32 tiles: lane (g, c) holds K[key 16 kt + c][d = 32 s + 8 g .. + 7]
+    const int c15 = lane & 15;
+    bf16x8 kf16[2][2], vf16[2][2];
+    float kmask16[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + 32 * w + 16 * kt + c15;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf16[kt][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rk, (int)(key * p.k_rs * 2) + (32 * s + 8 * g) * 2, 0, 0));
+            vf16[kt][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(key * p.v_rs * 2) + (32 * s + 8 * g) * 2, 0, 0));
+        }
+        kmask16[kt] = (RAGGED && key >= p.S) ? -1.0e30f : 0.f;
+    }
+#else
     bf16x8 kf[4], vf[4];
     {
         const int key = key0 + 32 * w + r;
@@ -243,8 +266,20 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         }
     }
     const float kmask = (RAGGED && (key0 + 32 * w + r) >= p.S) ? -1.0e30f : 0.f;
+#endif
 
     // ---- per-lane LDS offsets (identical to csrc/attn_bwd.hip) ----
+#if VT_M16
+    // Q / dO tile image, swizzle row & 6.  Row fragment (q-tile, k-step s): lane (g, c) reads row c, chunk 4 s + g; a q-tile is 2048 B further.
+    // Transposed fragment (d-tile dt) of a 32-query k-step: group g takes the 4-row blocks at rows 4 g and 16 + 4 g (k-slot j of the group =
+    // query 4 g + j for j < 4, 16 + 4 g + j - 4 above: the order in which two stacked accumulator tiles supply P / dS), columns 16 dt .. + 15
+    int rowrd16[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) rowrd16[s_] = c15 * 128 + (((4 * s_ + g) ^ (c15 & 6)) << 4);
+    int trA16[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) trA16[dt] = (4 * g + ql) * 128 + (((2 * dt + (pl >> 1)) ^ ((4 * g + ql) & 6)) << 4) + (pl & 1) * 8;
+#else
     int rowrd[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) rowrd[s] = r * 128 + (((2 * s + h) ^ swz_f(r)) << 4);
@@ -256,6 +291,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             const int fx = ((ql >> 1) << 2) | (sec << 1) | h;
             trA[dt][sec] = (4 * h + ql + 8 * sec) * 128 + (((4 * dt + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
         }
+#endif
 #if VT_DQ16
     // dQ phase: the 64x64 block as sixteen 16x16 tiles (v_mfma_f32_16x16x32_bf16), two per wave: q rows 16 qt .., d columns
     // 32 dh + {0, 16}.  A = dS^T (rows q, k = key) and B = K^T (rows d, k = key) both come from transposed reads: group
@@ -344,7 +380,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 16 * (w & 3) + 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ swz_f(row);
+        const int c = (lane & 7) ^ (VT_M16 ? (row & 6) : swz_f(row));
         dma_vq[j] = (int)(row * p.q_rs * 2) + c * 16;
         dma_vdo[j] = (int)(row * p.do_rs * 2) + c * 16;
     }
@@ -407,11 +443,19 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     };
 
 #endif
+#if VT_M16
+    f32x4 dk16[4][2], dv16[4][2];         // [d-tile][key-tile]: dK^T / dV^T, lane (g, c) holds d = 16 dt + 4 g + i of key 16 kt + c
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { dk16[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv16[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#else
     f32x16 dk_acc[2], dv_acc[2];          // [dt]: dK^T / dV^T of this wave's 32 keys
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk_acc[c][i] = 0.f; dv_acc[c][i] = 0.f; }
+#endif
 
     const float sc = p.scale_log2;
     const int nsteps = (p.S + 63) / 64;
@@ -453,6 +497,36 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     prefetch(0);
     // S'' / dP' of q-half 0 (initialised with the row constants) and the two-deep ring of Q / dO row operands are carried from step to
     // step: the first reads of step t + 1 are issued right after the barrier of step t, before anything else
+#if VT_M16
+    // 16 x 16 tiles: s16[q-half][q-tile][key-tile] (lane (g, c): query 16 qt + 4 g + i, key 16 kt + c); row-operand ring of two (q-tile, k-step)
+    // items; item n of a q-half = (k-step n >> 1, q-tile n & 1)
+    f32x4 s16[2][2][2], p16[2][2][2];
+    bf16x8 qa16[2], doa16[2];
+    // the row constants go straight into the accumulators of BOTH key tiles.  (Kept in registers of their own as the C operand of the first
+    // k-step's MFMAs -- one LDS value for two tiles, no spill -- measured slower: 6.94-7.15 vs 6.66-6.77 ms at B=1, same box.)
+    auto rd_init16 = [&](const float* lsel_, int qs, int qt, int which) {    // which: 0 = S'' (-lse2 / c [+ key mask]), 1 = dP' (-delta)
+        const f32x4 a = *(const f32x4*)(lsel_ + 64 * which + 32 * qs + 16 * qt + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (which == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s16[qs][qt][kt][e] = RAGGED ? a[e] + kmask16[kt] : a[e];
+            } else p16[qs][qt][kt] = a;
+        }
+    };
+    auto rd_rows16 = [&](const char* qimg_, const char* doimg_, int qs, int n) {
+        const int off = qs * 4096 + (n & 1) * 2048 + rowrd16[n >> 1];
+        qa16[n & 1] = *(const bf16x8*)(qimg_ + off);
+        doa16[n & 1] = *(const bf16x8*)(doimg_ + off);
+    };
+    auto rd_first = [&](int bufn) {
+        const char* qn = smem + QTILE + bufn * 16384;
+        const float* ln = (const float*)(smem + LSEOFF + bufn * 512);
+        rd_init16(ln, 0, 0, 0); rd_init16(ln, 0, 0, 1); rd_init16(ln, 0, 1, 0); rd_init16(ln, 0, 1, 1);
+        rd_rows16(qn, qn + 8192, 0, 0); rd_rows16(qn, qn + 8192, 0, 1);
+        FENCE();
+    };
+#else
     f32x16 sacc[2], pacc[2];
     bf16x8 qa[PF_ROWN], doa[PF_ROWN];
     auto rd_init = [&](const float* lsel_, int qs, int g0, int g1) {
@@ -475,6 +549,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         for (int s_ = 0; s_ < PF_ROWN; ++s_) rd_rows(qn, qn + 8192, 0, s_);
         FENCE();
     };
+#endif
 #if PF_R0
     rd_first(0);
 #endif
@@ -497,7 +572,80 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         char* dsimg = smem + DSIMG + buf * 32768;
         STAMP(1, stamp_dummy);
 
-#if VT_PF
+#if VT_PF && VT_M16
+        {
+            // the schedule of the 32 x 32 x 16 body below, on 16 x 16 x 32 tiles: per q-half a segment of 16 S'' / dP' MFMAs (four items of
+            // (k-step, q-tile) x (key-tile, S | dP)), the exp2 block, a segment of 16 dV / dK MFMAs (four d-tiles x (key-tile, dV | dK));
+            // every segment's operand reads are issued during the one before, pinned by the fences
+            bf16x8 doT16[4], qT16[4];
+            unsigned pw16[2][2][2], dw16[2][2][2];
+            auto rd_tr16 = [&](int qs, int dt) {
+                const int ro = qs * 4096 + trA16[dt];
+                doT16[dt] = tr_pair(doimg + ro, doimg + ro + 2048);
+                qT16[dt] = tr_pair(qimg + ro, qimg + ro + 2048);
+            };
+            rd_first(buf);
+            FENCE();
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int ks = n >> 1, qt = n & 1;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        s16[qs][qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa16[n & 1], kf16[kt][ks], s16[qs][qt][kt], 0, 0, 0);
+                        p16[qs][qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doa16[n & 1], vf16[kt][ks], p16[qs][qt][kt], 0, 0, 0);
+                    }
+                    if (n + 2 < 4) rd_rows16(qimg, doimg, qs, n + 2);        // into the slot these MFMAs just read
+                    if (n >= 2) rd_tr16(qs, n - 2);
+                    FENCE();
+                }
+                rd_tr16(qs, 2); rd_tr16(qs, 3);                               // land under the exp2 block
+                FENCE();
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float p0 = __builtin_amdgcn_exp2f(PRESCALED ? s16[qs][qt][kt][2 * i] : s16[qs][qt][kt][2 * i] * sc);
+                            const float p1 = __builtin_amdgcn_exp2f(PRESCALED ? s16[qs][qt][kt][2 * i + 1] : s16[qs][qt][kt][2 * i + 1] * sc);
+                            pw16[qt][kt][i] = pack2(p0, p1);
+                            dw16[qt][kt][i] = pack2(p0 * p16[qs][qt][kt][2 * i], p1 * p16[qs][qt][kt][2 * i + 1]);
+                        }
+                FENCE();
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        const u32x4 pb4 = {pw16[0][kt][0], pw16[0][kt][1], pw16[1][kt][0], pw16[1][kt][1]};
+                        const u32x4 db4 = {dw16[0][kt][0], dw16[0][kt][1], dw16[1][kt][0], dw16[1][kt][1]};
+                        dv16[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT16[dt], __builtin_bit_cast(bf16x8, pb4), dv16[dt][kt], 0, 0, 0);
+                        dk16[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT16[dt], __builtin_bit_cast(bf16x8, db4), dk16[dt][kt], 0, 0, 0);
+                    }
+                    if (qs == 0) {                      // the other q-half's first reads ride under these MFMAs
+                        rd_init16(lsel, 1, dt >> 1, dt & 1);
+                        if (dt >= 2) rd_rows16(qimg, doimg, 1, dt - 2);
+                    }
+                    FENCE();
+                }
+                // dS image (format of the 32 x 32 body: row = key, 8 bytes = four consecutive queries): tile (qt, kt) -> row 32 w + 16 kt + c,
+                // queries 32 qs + 16 qt + 4 g + (0..3) = chunk 4 qs + 2 qt + (g >> 1), half g & 1
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const int krow = 32 * w + 16 * kt + c15;
+                    char* drow = dsimg + krow * 128 + 8 * (g & 1);
+                    const int fk = swz_f(krow);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        const u32x2 two = {dw16[qt][kt][0], dw16[qt][kt][1]};
+                        *(u32x2*)(drow + (((4 * qs + 2 * qt + (g >> 1)) ^ fk) << 4)) = two;
+                    }
+                }
+                FENCE();
+            }
+        }
+#elif VT_PF
         {
             // The compiler's own order issues every operand read right before the MFMA that needs it (one LDS round trip exposed per
             // k-step: profiles/r02_attn_bwd_stamps_before_*.txt -- 650-950 cycles per 8-MFMA segment against 256 of matrix-pipe time).
@@ -845,6 +993,26 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 
     // ---- epilogue: dK^T, dV^T accumulators -> dk[key][d], dv[key][d] ----
     const float dk_mul = PRESCALED ? 0.6931471805599453f : p.scale;
+#if VT_M16
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + 32 * w + 16 * kt + c15;
+        if (key < p.S) {
+            bf16_t* dkp = p.dk + (size_t)b * p.dk_bs + (size_t)key * p.dk_rs + head * 64;
+            bf16_t* dvp = p.dv + (size_t)b * p.dv_bs + (size_t)key * p.dv_rs + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 a, c;
+                a[0] = pack2(dk16[dt][kt][0] * dk_mul, dk16[dt][kt][1] * dk_mul);
+                a[1] = pack2(dk16[dt][kt][2] * dk_mul, dk16[dt][kt][3] * dk_mul);
+                c[0] = pack2(dv16[dt][kt][0], dv16[dt][kt][1]);
+                c[1] = pack2(dv16[dt][kt][2], dv16[dt][kt][3]);
+                *(u32x2*)(dkp + 16 * dt + 4 * g) = a;
+                *(u32x2*)(dvp + 16 * dt + 4 * g) = c;
+            }
+        }
+    }
+#else
     {
         const int key = key0 + 32 * w + r;
         if (key < p.S) {
@@ -864,6 +1032,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 }
         }
     }
+#endif
 }
 
 #else

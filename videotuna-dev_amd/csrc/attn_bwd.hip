@@ -108,6 +108,11 @@
                       // row & 6 (conflict-free for the 16-row ds_read_b128 fragments AND the transposed reads of a 16 x 16 x 32 operand);
                       // the dS image keeps its format, so the dQ phase is untouched.  Same box, B=1: 6.58-6.77 against 6.90-6.95 ms (-4.7 %).
                       // The instrumented / ablation builds (VT_STAMP, VT_STATMFMA, VT_ABL, PF_R0, VT_DMA_LATE) exist for the 32 x 32 body only: -DVT_M16=0.
+#ifndef VT_DQM16
+#define VT_DQM16 0        // 1 = the dQ product of waves 0..3 as four 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 per wave (eight 32-key k-steps) instead of one
+#endif                  // 32 x 32 tile of v_mfma_f32_32x32x16_bf16 (sixteen 16-key k-steps); the hand-off tiles carry the registers as they are.  Parity-clean
+                        // but measured SLOWER on the same box (7.09 vs 6.58-6.69 ms, B=1): a register's atomic then covers 4 rows x 64 B instead of
+                        // 2 rows x 128 B, and twice the transposed reads are in flight per k-step.  Off.
 #ifndef VT_DMA_LATE
 #define VT_DMA_LATE 0  // 1 = waves 4..7 issue their staging pieces inside the S phase instead of right behind the barrier: measured slower (13.14 vs 12.83 ms, B=2)
 #endif
@@ -319,7 +324,24 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
         trQA[sec] = row + (((4 * qs_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
         trQB[sec] = row + (((4 * dt_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
     }
+#if VT_DQM16
+    // 16 x 16 x 32 operands of the dQ product (the addressing of the VT_DQ16 variant): group g takes key rows 8 g + 4 sec + ql of every 32-key
+    // k-step, 16 columns wide -- q-tiles 2 qs_w + a of the dS image (A), d-tiles 2 dt_w + b of the K image (B)
+    int trq16m[2][2], trk16m[2][2];
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+        const int row = 8 * g + 4 * sec + ql;
+        const int fxr = swz_f(row);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            trq16m[a][sec] = row * 128 + (((2 * (2 * qs_w + a) + (pl >> 1)) ^ fxr) << 4) + (pl & 1) * 8;
+            trk16m[a][sec] = row * 128 + (((2 * (2 * dt_w + a) + (pl >> 1)) ^ fxr) << 4) + (pl & 1) * 8;
+        }
+    }
+    const int dq_voff = (int)((32 * qs_w + 4 * g) * p.dq_rs * 4) + (32 * dt_w + (lane & 15)) * 4;
+#else
     const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
+#endif
     const int dq_rowb = (int)(p.dq_rs * 4);
 #endif
     const int fr = swz_f(r);
@@ -874,6 +896,12 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #endif
             if (has_prod) s_ready = __builtin_amdgcn_readfirstlane(pf_ready);      // the barrier drained the memory pipeline
             const int s_cons = has_cons ? __builtin_amdgcn_readfirstlane(pf_cons) : 0;
+#if VT_PF && VT_DQM16
+            f32x4 dqt[2][2];                          // [q-tile a][d-tile b]; piece j = 2 a + b of the hand-off tile
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dqt[j >> 1][j & 1] = has_prod ? *(const f32x4*)(stage + wu * 4096 + j * 1024 + lane * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
             f32x16 dq_acc;
             if (has_prod) {
 #pragma unroll
@@ -886,6 +914,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dq_acc[i] = 0.f;
             }
+#endif
 #if VT_PF
             if (has_prod) __builtin_amdgcn_s_waitcnt(0xc07f);                             // the stage has been read: the next DMA may land
             if (has_cons && t > 0) {
@@ -894,7 +923,30 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             }
             prefetch(t + 1);
 #endif
-#if VT_PF
+#if VT_PF && VT_DQM16
+            {
+                bf16x8 fa[2][2], fb[2][2];                    // [ring slot][tile]: two 32-key k-steps of operands in flight
+                auto rd_dq16 = [&](int s3) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        fa[s3 & 1][a] = tr_pair(dsimg + s3 * 4096 + trq16m[a][0], dsimg + s3 * 4096 + trq16m[a][1]);
+                        fb[s3 & 1][a] = tr_pair(smem + KIMG + s3 * 4096 + trk16m[a][0], smem + KIMG + s3 * 4096 + trk16m[a][1]);
+                    }
+                };
+                rd_dq16(0); rd_dq16(1);
+                FENCE();
+#pragma unroll
+                for (int s3 = 0; s3 < 8; ++s3) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2)
+                            dqt[a][b2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s3 & 1][a], fb[s3 & 1][b2], dqt[a][b2], 0, 0, 0);
+                    if (s3 + 2 < 8) rd_dq16(s3 + 2);
+                    FENCE();
+                }
+            }
+#elif VT_PF
             {
                 bf16x8 fa[DQ_RING], fb[DQ_RING];              // DQ_RING k-steps of operands in flight (the compiler's order: one, waited for at once)
                 auto rd_dq = [&](int s3) {
@@ -932,7 +984,9 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 dq_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, dq_acc, 0, 0, 0);
             }
 #endif
+#if !(VT_PF && VT_DQM16)
             STAMP(10, dq_acc[15]);
+#endif
             if (has_cons) {
                 const int a = base + t;
                 int need = a - CH_R + 1;
@@ -946,7 +1000,11 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if VT_PF && VT_DQM16
+                    const f32x4 v = dqt[j >> 1][j & 1];
+#else
                     const f32x4 v = {dq_acc[4 * j], dq_acc[4 * j + 1], dq_acc[4 * j + 2], dq_acc[4 * j + 3]};
+#endif
                     if (l2_next)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt_mine, tile_voff + j * 1024, (a % CH_R) * 16384, 0);
                     else
@@ -954,7 +1012,16 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                 }
             } else {
                 const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
-#if VT_ABL == 2
+#if VT_PF && VT_DQM16
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)          // register e of tile (a, b) = q row 16 a + 4 g + e, d = 16 b + (lane & 15)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2)
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dqt[a][b2][e] * p.scale, rdq, dq_voff,
+                                                                            soff + (16 * a + e) * dq_rowb + 64 * b2, VT_ATOM_AUX);
+#elif VT_ABL == 2
 #pragma unroll
                 for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));
                 (void)soff;

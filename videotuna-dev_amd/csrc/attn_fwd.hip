@@ -377,6 +377,191 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
     }
 }
 
+
+#ifndef VT_FWD_M16
+#define VT_FWD_M16 1     // 1 = the pre-scaled-q forward (the training path) runs attn_fwd_hd64_m16_kernel: both products on v_mfma_f32_16x16x32_bf16
+#endif                   // tiles (same cycles per flop as 32x32x16; the chip holds a higher clock on this shape under load -- gemm_big_bf16.hip)
+
+// The lazy-max forward on 16 x 16 x 32 tiles.  A wave owns 32 queries = two q-tiles; S^T tile (key-tile kt, q-tile qt): lane (g = lane >> 4,
+// c = lane & 15) holds query 16 qt + c and keys 16 kt + 4 g + (0..3), so the row statistics are lane-local up to the four lane groups
+// (combined only when a rescale happens and at the end).  P^T of two stacked key tiles, packed to bf16, is the B operand of
+// O^T += V^T P^T (k-slot j of group g = key 4 g + j for j < 4, 16 + 4 g + j - 4 above); the V^T fragments follow that order through two
+// transposed reads each.  K image: swizzle (key >> 1) & 7 (conflict-free 16-row ds_read_b128 fragments); V image: swizzle key & 6
+// (conflict-free transposed reads of a 16 x 16 x 32 operand).
+__global__ __launch_bounds__(256, 2) void attn_fwd_hd64_m16_kernel(AttnFwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];   // 2 x (K 8 KiB + V 8 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4, ql = (lane & 15) >> 2, pl = lane & 3;
+    const int nqt = (p.S + 127) / 128;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int qtb = id % nqt;
+    const int bh = id / nqt;
+    const int head = bh % p.H, b = bh / p.H;
+    const int q0 = qtb * 128 + wave * 32;
+
+    const bf16_t* qb = p.q + (size_t)b * p.q_bs + head * 64;
+    const bf16_t* kb = p.k + (size_t)b * p.k_bs + head * 64;
+    const bf16_t* vb = p.v + (size_t)b * p.v_bs + head * 64;
+    __amdgpu_buffer_rsrc_t rk = make_rsrc(kb, (unsigned)((long long)(p.S - 1) * p.k_rs * 2 + 128));
+    __amdgpu_buffer_rsrc_t rv = make_rsrc(vb, (unsigned)((long long)(p.S - 1) * p.v_rs * 2 + 128));
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + 16 qt + c][32 s + 8 g .. + 7]
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int qrow = q0 + 16 * qt + c;
+        if (qrow > p.S - 1) qrow = p.S - 1;       // clamp: rows past the end are computed but never stored
+        const bf16_t* qp = qb + (size_t)qrow * p.q_rs + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[qt][s] = *(const bf16x8*)(qp + 32 * s);
+    }
+    // LDS-DMA staging: wave w moves the 1-KiB pieces w and w + 4 (8 keys x 128 B) of K and of V; the swizzle is applied to the SOURCE chunk
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int kd_voff[2], vd_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = 8 * (wv + 4 * j) + (lane >> 3);
+        kd_voff[j] = (int)(key * p.k_rs * 2) + (((lane & 7) ^ ((key >> 1) & 7)) << 4);
+        vd_voff[j] = (int)(key * p.v_rs * 2) + (((lane & 7) ^ (key & 6)) << 4);
+    }
+    auto dma = [&](int t, int buf) {
+        const int ks = (int)((long long)t * FK * p.k_rs * 2);
+        const int vs = (int)((long long)t * FK * p.v_rs * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* dst = smem + buf * 16384 + (wv + 4 * j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kd_voff[j], ks, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + 8192), 16, vd_voff[j], vs, 0, 0);
+        }
+    };
+    int kfo[2];                                   // K fragment (key-tile at + 2048 kt), k-step s: row c, chunk 4 s + g
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kfo[s] = c * 128 + (((4 * s + g) ^ ((c >> 1) & 7)) << 4);
+    int vfo[4];                                   // V^T fragment of d-tile dt: block rows 4 g + ql (second block 16 rows further), k-step at + 4096 s'
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vfo[dt] = 8192 + (4 * g + ql) * 128 + (((2 * dt + (pl >> 1)) ^ ((4 * g + ql) & 6)) << 4) + (pl & 1) * 8;
+
+    f32x4 o16[4][2];                              // O^T tiles [d-tile][q-tile]: lane holds d = 16 dt + 4 g + (0..3) of query 16 qt + c
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o16[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto group_max = [&](float x) {               // over the four lane groups of a query column
+        x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F)));      // lane ^ 16
+        return fmaxf(x, __shfl_xor(x, 32, 64));
+    };
+
+    const int nt = (p.S + FK - 1) / FK;
+    dma(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma(t + 1, buf ^ 1);
+        const char* base = smem + buf * 16384;
+        f32x4 st[4][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 kf = *(const bf16x8*)(base + kt * 2048 + kfo[s]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], s == 0 ? negm[qt] : st[kt][qt], 0, 0, 0);
+            }
+        if ((t + 1) * FK > p.S) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (t * FK + 16 * kt + 4 * g + i >= p.S) { st[kt][0][i] = NEG_BIG; st[kt][1][i] = NEG_BIG; }
+        }
+        float mx[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            mx[qt] = st[0][qt][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx[qt] = fmaxf(mx[qt], st[kt][qt][i]);
+        }
+        if (t == 0 || !__all(fmaxf(mx[0], mx[1]) <= LAZY_THR)) {            // wave-uniform; the lanes' partial maxima decide
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float mq = group_max(mx[qt]);
+                const float delta = (t == 0) ? mq : fmaxf(mq, 0.f);
+                const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run[qt] += delta;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o16[dt][qt][i] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st[kt][qt][i] -= delta;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) negm[qt][i] = -m_run[qt];
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(st[kt][qt][i]);
+                    st[kt][qt][i] = pv;
+                    psum += pv;
+                }
+            l_run[qt] += psum;
+        }
+        // O^T += V^T P^T: two 32-key k-steps x four d-tiles x two q-tiles
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pf[qt][j] = (bf16_t)st[2 * s2][qt][j]; pf[qt][4 + j] = (bf16_t)st[2 * s2 + 1][qt][j]; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vp = base + vfo[dt] + s2 * 4096;
+                short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp));
+                short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(vp + 2048));
+                typedef __attribute__((ext_vector_type(8))) short short8v;
+                short8v v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 vt = __builtin_bit_cast(bf16x8, v8);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o16[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[qt], o16[dt][qt], 0, 0, 0);
+            }
+        }
+        __syncthreads();       // its vmcnt(0) also retires the next tile's LDS-DMA
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l_tot = l_run[qt];
+        l_tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, l_tot), 0x401F));
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + 16 * qt + c;
+        if (qrow < p.S) {
+            bf16_t* op = p.o + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 w;
+                w[0] = pack2(o16[dt][qt][0] * inv, o16[dt][qt][1] * inv);
+                w[1] = pack2(o16[dt][qt][2] * inv, o16[dt][qt][3] * inv);
+                *(u32x2*)(op + 16 * dt + 4 * g) = w;
+            }
+            if (g == 0) p.lse2[((size_t)b * p.H + head) * p.S + qrow] = m_run[qt] + __builtin_amdgcn_logf(l_tot);
+        }
+    }
+}
+
 extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float* lse2,
                                 int B, int H, int S,
                                 long long q_rs, long long k_rs, long long v_rs, long long o_rs,
@@ -396,7 +581,9 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.bias_t = nullptr;
     const int nqt = (S + FQ - 1) / FQ;
-    if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
+    if (q_prescaled && VT_FWD_M16 && VT_FWD_WAVES == 4 && VT_FWD_DMA)
+        hipLaunchKernelGGL(attn_fwd_hd64_m16_kernel, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
+    else if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }

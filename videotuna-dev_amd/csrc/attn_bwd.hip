@@ -111,8 +111,8 @@
 #ifndef VT_DQM16
 #define VT_DQM16 0        // 1 = the dQ product of waves 0..3 as four 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 per wave (eight 32-key k-steps) instead of one
 #endif                  // 32 x 32 tile of v_mfma_f32_32x32x16_bf16 (sixteen 16-key k-steps); the hand-off tiles carry the registers as they are.  Parity-clean
-                        // but measured SLOWER on the same box (7.09 vs 6.58-6.69 ms, B=1): a register's atomic then covers 4 rows x 64 B instead of
-                        // 2 rows x 128 B, and twice the transposed reads are in flight per k-step.  Off.
+                        // but measured SLOWER on the same box (7.09 vs 6.58-6.69 ms, B=1) -- also with the registers of the two d-tiles exchanged by
+                        // v_permlane16_swap so that every atomic covers 2 rows x 128 B again (7.15-7.32 vs 6.86-6.88): not the atomics' granularity.  Off.
 #ifndef VT_DMA_LATE
 #define VT_DMA_LATE 0  // 1 = waves 4..7 issue their staging pieces inside the S phase instead of right behind the barrier: measured slower (13.14 vs 12.83 ms, B=2)
 #endif
@@ -338,7 +338,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             trk16m[a][sec] = row * 128 + (((2 * (2 * dt_w + a) + (pl >> 1)) ^ fxr) << 4) + (pl & 1) * 8;
         }
     }
-    const int dq_voff = (int)((32 * qs_w + 4 * g) * p.dq_rs * 4) + (32 * dt_w + (lane & 15)) * 4;
+    const int dq_voff = (int)((32 * qs_w + 8 * (g >> 1)) * p.dq_rs * 4) + (32 * dt_w + 16 * (g & 1) + (lane & 15)) * 4;   // after the lane-row swap
 #else
     const int dq_voff = (int)((32 * qs_w + 4 * h) * p.dq_rs * 4) + (32 * dt_w + r) * 4;
 #endif
@@ -1013,14 +1013,19 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
             } else {
                 const int soff = (int)((long long)t * 64 * p.dq_rs * 4);
 #if VT_PF && VT_DQM16
+                // register e of tile (a, b) = q row 16 a + 4 g + e, d = 16 b + (lane & 15): one atomic would cover 4 rows x 64 B.  v_permlane16_swap
+                // of the two d-tiles' registers (odd 16-lane rows of the first <-> even rows of the second) makes every atomic cover 2 rows x 128 B
+                // again: first result q = 16 a + 8 (G >> 1) + e, second q = 16 a + 4 + 8 (G >> 1) + e, both d = 16 (G & 1) + (lane & 15), G = lane >> 4
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)          // register e of tile (a, b) = q row 16 a + 4 g + e, d = 16 b + (lane & 15)
-#pragma unroll
-                        for (int b2 = 0; b2 < 2; ++b2)
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(dqt[a][b2][e] * p.scale, rdq, dq_voff,
-                                                                            soff + (16 * a + e) * dq_rowb + 64 * b2, VT_ATOM_AUX);
+                    for (int e = 0; e < 4; ++e) {
+                        // (inline asm: hipcc 7.2 feeds the FIRST result of __builtin_amdgcn_permlane16_swap to both users here)
+                        float x0 = dqt[a][0][e] * p.scale, x1 = dqt[a][1][e] * p.scale;
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(x0, rdq, dq_voff, soff + (16 * a + e) * dq_rowb, VT_ATOM_AUX);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(x1, rdq, dq_voff, soff + (16 * a + 4 + e) * dq_rowb, VT_ATOM_AUX);
+                    }
 #elif VT_ABL == 2
 #pragma unroll
                 for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(dq_acc[i]));

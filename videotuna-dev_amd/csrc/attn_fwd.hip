@@ -379,8 +379,11 @@ __global__ __launch_bounds__(FWD_THREADS, (VT_FWD_WAVES == 8 ? 1 : 2)) void attn
 
 
 #ifndef VT_FWD_M16
-#define VT_FWD_M16 1     // 1 = the pre-scaled-q forward (the training path) runs attn_fwd_hd64_m16_kernel: both products on v_mfma_f32_16x16x32_bf16
-#endif                   // tiles (same cycles per flop as 32x32x16; the chip holds a higher clock on this shape under load -- gemm_big_bf16.hip)
+#define VT_FWD_M16 0     // 1 = the pre-scaled-q forward (the training path) runs attn_fwd_hd64_m16_kernel: both products on v_mfma_f32_16x16x32_bf16
+#endif                   // tiles (same cycles per flop as 32x32x16; the chip holds a higher clock on this shape under load -- gemm_big_bf16.hip).
+                         // Parity-clean.  Back to back in a loop (tools/kbench.py attn, B=1) it is 3.5 % FASTER than the 32x32x16 kernel (2.48 vs 2.57 ms);
+                         // inside the training step (bench.py, B=4, same box, two rounds) it is 1.5 % SLOWER (9.09-9.15 vs 8.94-9.03 ms per launch):
+                         // a 9-ms kernel between GEMMs does not sit in the clock regime of a sustained loop.  The step decides: off.
 
 // The lazy-max forward on 16 x 16 x 32 tiles.  A wave owns 32 queries = two q-tiles; S^T tile (key-tile kt, q-tile qt): lane (g = lane >> 4,
 // c = lane & 15) holds query 16 qt + c and keys 16 kt + 4 g + (0..3), so the row statistics are lane-local up to the four lane groups

@@ -91,6 +91,7 @@ int vt_silu_bwd(const float* dy, const void* x, float* dx, long long n, void* st
  * lse2[b,h,s] = log2(sum_j exp(scale * q.k_j)) (fp32), kept for the backward.
  * q_prescaled != 0: q was already multiplied by softmax_scale*log2(e) (vt_qk_layernorm_fwd's q_scale), so the
  * kernels use exp2 of the raw scores; dq is still the gradient wrt the UNscaled q_hat, dk wrt k_hat.
+ * (forward only) q_prescaled == 2: the same on the 16x16x32-MFMA variant of the kernel (identical contract; not the default).
  * Replaces: F.scaled_dot_product_attention in diffusers CogVideoXAttnProcessor2_0 (cogvideo_pl.py:865-871). */
 int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, void* o, float* lse2,
                      int B, int H, int S,

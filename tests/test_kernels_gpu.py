@@ -112,10 +112,13 @@ def _prescale(qkv, pre):
     return dq, ref
 
 
-@pytest.mark.parametrize("pre", [False, True])
+@pytest.mark.parametrize("pre", [False, True, "tiles16"])
 @pytest.mark.parametrize("B,S,H,spike", [(1, 64, 1, False), (2, 100, 2, False), (1, 333, 3, True), (1, 1250, 2, False)])
 def test_attn_fwd(dev, B, S, H, spike, pre):
+    """pre = "tiles16": the 16x16x32-MFMA variant of the pre-scaled forward (not the default: slower inside the training step)"""
     from vt355 import ops
+    tiles16 = pre == "tiles16"
+    pre = bool(pre)
     g = torch.Generator().manual_seed(S)
     qkv = _qkv(B, S, H, g, spike)
     qkv_dev, qkv_ref = _prescale(qkv, pre)
@@ -124,7 +127,7 @@ def test_attn_fwd(dev, B, S, H, spike, pre):
     d = qkv_dev.to(dev, BF).view(B, S, 3 * H * 64)
     o = torch.empty(B, S, H * 64, dtype=BF, device=dev)
     lse2 = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-    ops.attn_fwd(d[:, :, :H * 64], d[:, :, H * 64:2 * H * 64], d[:, :, 2 * H * 64:], o, lse2, B, H, S, q_prescaled=pre)
+    ops.attn_fwd(d[:, :, :H * 64], d[:, :, H * 64:2 * H * 64], d[:, :, 2 * H * 64:], o, lse2, B, H, S, q_prescaled=pre, tiles16=tiles16)
     close(o.view(B, S, H, 64).permute(0, 2, 1, 3), o_ref, 2e-2, 1e-2, "attn out")
     close(lse2 * math.log(2.0), lse_ref, 1e-4, 2e-3, "lse")
 

@@ -584,7 +584,7 @@ extern "C" int vt_attn_fwd_hd64(const void* q, const void* k, const void* v, voi
     p.scale_log2 = softmax_scale * 1.4426950408889634f;
     p.bias_t = nullptr;
     const int nqt = (S + FQ - 1) / FQ;
-    if (q_prescaled && VT_FWD_M16 && VT_FWD_WAVES == 4 && VT_FWD_DMA)
+    if (q_prescaled && (VT_FWD_M16 || q_prescaled == 2) && VT_FWD_WAVES == 4 && VT_FWD_DMA)      // q_prescaled == 2: the 16x16x32 variant on request
         hipLaunchKernelGGL(attn_fwd_hd64_m16_kernel, dim3(nqt * H * B), dim3(256), 0, (hipStream_t)stream, p);
     else if (q_prescaled) hipLaunchKernelGGL(attn_fwd_hd64_kernel<true>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_hd64_kernel<false>, dim3(nqt * H * B), dim3(FWD_THREADS), 0, (hipStream_t)stream, p);

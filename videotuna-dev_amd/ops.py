@@ -192,8 +192,11 @@ def silu_bwd(dy_f32, x_pre, dx_f32):
     check(load_library().vt_silu_bwd(dy_f32.data_ptr(), x_pre.data_ptr(), dx_f32.data_ptr(), dy_f32.numel(), _stream()), "vt_silu_bwd")
 
 
-def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None, q_prescaled: bool = False):
-    """q,k,v,o: views whose element (b,s,h,d) is at base + b*bs + s*rs + h*64 + d; given as 3-d [B,S,>=H*64]."""
+def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = None, q_prescaled: bool = False, tiles16: bool = False):
+    """q,k,v,o: views whose element (b,s,h,d) is at base + b*bs + s*rs + h*64 + d; given as 3-d [B,S,>=H*64].
+    tiles16 (with q_prescaled): the 16x16x32-MFMA variant of the kernel (same results; measured slower inside the training step, kept tested)"""
+    if tiles16 and not q_prescaled:
+        raise ValueError("the 16x16x32 forward exists for pre-scaled q only")
     for n, t in (("q", q), ("k", k), ("v", v), ("o", o)):
         _req(t, BF16, n, 3)
     scale = 1.0 / math.sqrt(64) if scale is None else scale
@@ -201,7 +204,7 @@ def attn_fwd(q, k, v, o, lse2, B: int, H: int, S: int, scale: Optional[float] = 
     with _timed("attn_fwd"):
       check(lib.vt_attn_fwd_hd64(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse2.data_ptr(), B, H, S,
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1),
-                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, int(q_prescaled), _stream()),
+                               q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, 2 if tiles16 else int(q_prescaled), _stream()),
           "vt_attn_fwd_hd64")
 
 

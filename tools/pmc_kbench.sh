@@ -23,6 +23,11 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0]
         if pat in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                ns = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])      # effective clock of the dispatch: GRBM_GUI_ACTIVE / 8 XCDs / wall time
+                if ns > 0:
+                    agg[k]["effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / wall)"].append(float(r["Counter_Value"]) / 8.0 / ns)
+                    agg[k]["wall_ms (counter pass)"].append(ns / 1e6)
 with open(out + "/summary.txt", "w") as fo:
     for k in agg:
         fo.write(k + "\n")

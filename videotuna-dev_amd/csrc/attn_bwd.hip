@@ -108,6 +108,10 @@
                       // row & 6 (conflict-free for the 16-row ds_read_b128 fragments AND the transposed reads of a 16 x 16 x 32 operand);
                       // the dS image keeps its format, so the dQ phase is untouched.  Same box, B=1: 6.58-6.77 against 6.90-6.95 ms (-4.7 %).
                       // The instrumented / ablation builds (VT_STAMP, VT_STATMFMA, VT_ABL, PF_R0, VT_DMA_LATE) exist for the 32 x 32 body only: -DVT_M16=0.
+#ifndef VT_DS4
+#define VT_DS4 (VT_M16 && !VT_DQM16)   // 1 = the dS image is swizzled at 8-byte granularity with four row bits (swz4): the S phase's ds_write_b64 of a 16-lane
+#endif                             // group then hit 16 distinct 8-byte positions (with the 16-byte swizzle two lanes shared every position: 256 conflict
+                                   // cycles per workgroup-step, SQ_LDS_BANK_CONFLICT) and the dQ phase's transposed reads stay conflict-free
 #ifndef VT_DQM16
 #define VT_DQM16 0        // 1 = the dQ product of waves 0..3 as four 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 per wave (eight 32-key k-steps) instead of one
 #endif                  // 32 x 32 tile of v_mfma_f32_32x32x16_bf16 (sixteen 16-key k-steps); the hand-off tiles carry the registers as they are.  Parity-clean
@@ -196,6 +200,7 @@ typedef int i32x4w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int swz_f(int row) {
     return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
 }
+__device__ __forceinline__ int swz4(int row) { return (((row >> 1) & 1) << 3) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 1) | (row & 1); }
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ swz_f(row)) << 4); }
 
 // two transposed 8-byte reads (rows +0..3 and rows +sec_stride) -> one 8 x bf16 MFMA operand
@@ -321,7 +326,11 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
     for (int sec = 0; sec < 2; ++sec) {
         const int fx = ((ql >> 1) << 2) | (h << 1) | sec;
         const int row = (8 * h + ql + 4 * sec) * 128;
+#if VT_DS4
+        trQA[sec] = row + (((2 * (4 * qs_w + 2 * (g & 1) + (pl >> 1)) + (pl & 1)) ^ swz4(8 * h + ql + 4 * sec)) << 3);
+#else
         trQA[sec] = row + (((4 * qs_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
+#endif
         trQB[sec] = row + (((4 * dt_w + 2 * (g & 1) + (pl >> 1)) ^ fx) << 4) + (pl & 1) * 8;
     }
 #if VT_DQM16
@@ -656,6 +665,15 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     const int krow = 32 * w + 16 * kt + c15;
+#if VT_DS4
+                    char* drow = dsimg + krow * 128;
+                    const int fk = swz4(krow);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        const u32x2 two = {dw16[qt][kt][0], dw16[qt][kt][1]};
+                        *(u32x2*)(drow + (((8 * qs + 4 * qt + g) ^ fk) << 3)) = two;          // 8-byte position = (query / 4) ^ swz4(key row)
+                    }
+#else
                     char* drow = dsimg + krow * 128 + 8 * (g & 1);
                     const int fk = swz_f(krow);
 #pragma unroll
@@ -663,6 +681,7 @@ __device__ __forceinline__ void BWD_BODY(const AttnBwdParams& p, char* smem, cha
                         const u32x2 two = {dw16[qt][kt][0], dw16[qt][kt][1]};
                         *(u32x2*)(drow + (((4 * qs + 2 * qt + (g >> 1)) ^ fk) << 4)) = two;
                     }
+#endif
                 }
                 FENCE();
             }

@@ -27,6 +27,18 @@ def main():
     which = sys.argv[1:] or ["gemm", "attn", "mem"]
     S, H, d = 17776, 30, 1920
     res = {}
+    if "attn128q" in which:   # HunyuanVideo attention (head_dim 128, 10 456 tokens, 24 heads), few launches: a PMC target
+        S1, H1 = 10456, 24
+        c1 = H1 * 128
+        j = torch.randn(1, S1, 3 * c1, device=dev).to(BF)
+        o1 = torch.empty(1, S1, c1, dtype=BF, device=dev); l1 = torch.empty(1, H1, S1, device=dev)
+        do1 = torch.randn(1, S1, c1, device=dev).to(BF); dj = torch.empty(1, S1, 3 * c1, dtype=BF, device=dev)
+        kv = torch.tensor([S1 - 56], dtype=torch.int32, device=dev)
+        for _ in range(3):
+            ops.attn128_fwd(j[:, :, :c1], j[:, :, c1:2 * c1], j[:, :, 2 * c1:], o1, l1, H1, 128 ** -0.5, kv_len=kv)
+            ops.attn128_bwd(j[:, :, :c1], j[:, :, c1:2 * c1], j[:, :, 2 * c1:], o1, do1, l1, dj[:, :, :c1], dj[:, :, c1:2 * c1], dj[:, :, 2 * c1:], H1, 128 ** -0.5, kv_len=kv)
+        torch.cuda.synchronize()
+        return
     if "attnq" in which:      # attention forward + backward, few launches: the PMC target (tools/pmc_kbench.sh)
         B = 2
         qkv = torch.randn(B, S, 3 * d, device=dev).to(BF)

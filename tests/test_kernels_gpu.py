@@ -472,6 +472,23 @@ def test_group_colsum(dev):
             close(o2[2 * b + seg], (x[rows] * yn[rows]).sum(0), 1e-4, 3e-3, "group sum of products")
 
 
+@pytest.mark.parametrize("M,D", [(4096, 320), (5003, 640), (9999, 1024), (4100, 8), (7001, 328)])
+def test_group_colsum_narrow_matrices(dev, M, D):
+    """plain column sums of a contiguous matrix with <= 1024 columns and >= 4096 rows take the row-flat kernel (the UNet's 320 / 640-channel bias
+    gradients); a strided view of the same data takes the general one -- both equal the fp64 sum, and the sum accumulates into the output"""
+    from vt355 import ops
+    g = torch.Generator().manual_seed(M + D)
+    x = rb(torch.randn(M, D, generator=g))
+    ref = x.double().sum(0)
+    o = torch.full((1, D), 3.0, device=dev)
+    ops.group_colsum(x.to(dev, BF), o)
+    close(o[0] - 3.0, ref.float(), 1e-4, 2e-3 * ref.abs().max().item(), "narrow colsum")
+    wide = torch.zeros(M, D + 8, dtype=BF, device=dev); wide[:, :D] = x.to(dev, BF)
+    o2 = torch.zeros(1, D, device=dev)
+    ops.group_colsum(wide[:, :D], o2, D=D)
+    close(o2[0], ref.float(), 1e-4, 2e-3 * ref.abs().max().item(), "strided colsum")
+
+
 # ------------------------------------------------------------------ error behaviour of the C-ABI
 def test_abi_rejects_bad_arguments(dev):
     """The library validates shapes / alignment on the host and returns a negative code (no launch, no fault): the Python

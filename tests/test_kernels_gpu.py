@@ -472,10 +472,11 @@ def test_group_colsum(dev):
             close(o2[2 * b + seg], (x[rows] * yn[rows]).sum(0), 1e-4, 3e-3, "group sum of products")
 
 
-@pytest.mark.parametrize("M,D", [(4096, 320), (5003, 640), (9999, 1024), (4100, 8), (7001, 328)])
+@pytest.mark.parametrize("M,D", [(4096, 320), (5003, 640), (9999, 1024), (4100, 8), (7001, 328), (4500, 324)])
 def test_group_colsum_narrow_matrices(dev, M, D):
-    """plain column sums of a contiguous matrix with <= 1024 columns and >= 4096 rows take the row-flat kernel (the UNet's 320 / 640-channel bias
-    gradients); a strided view of the same data takes the general one -- both equal the fp64 sum, and the sum accumulates into the output"""
+    """ungrouped column sums of a matrix with <= 1024 columns (a multiple of 8) and >= 4096 rows take the row-flat kernel (the UNet's 320 / 640-channel
+    bias and GroupNorm-parameter gradients), contiguous or strided, with or without the product with a normalised second operand; 324 columns fall
+    back to the general kernel -- all equal the fp64 sums, and the sums accumulate into the outputs"""
     from vt355 import ops
     g = torch.Generator().manual_seed(M + D)
     x = rb(torch.randn(M, D, generator=g))
@@ -487,6 +488,15 @@ def test_group_colsum_narrow_matrices(dev, M, D):
     o2 = torch.zeros(1, D, device=dev)
     ops.group_colsum(wide[:, :D], o2, D=D)
     close(o2[0], ref.float(), 1e-4, 2e-3 * ref.abs().max().item(), "strided colsum")
+    y = rb(torch.randn(M, D, generator=g) * 2 + 1)
+    mean = y.mean(1); rstd = 1.0 / (y.var(1, unbiased=False) + 1e-5).sqrt()
+    for stats in (False, True):
+        yn = ((y - mean[:, None]) * rstd[:, None]) if stats else y
+        ref2 = (x.double() * yn.double()).sum(0)
+        a = torch.zeros(1, D, device=dev); b2 = torch.full((1, D), -1.0, device=dev)
+        ops.group_colsum(wide[:, :D], a, y=y.to(dev, BF), out2=b2, mean=mean.to(dev) if stats else None, rstd=rstd.to(dev) if stats else None, D=D)
+        close(a[0], ref.float(), 1e-4, 2e-3 * ref.abs().max().item(), "colsum next to the product sums")
+        close(b2[0] + 1.0, ref2.float(), 1e-4, 3e-3 * ref2.abs().max().item(), "column sums of x * y")
 
 
 # ------------------------------------------------------------------ error behaviour of the C-ABI

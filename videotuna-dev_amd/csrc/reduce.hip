@@ -83,46 +83,65 @@ __global__ __launch_bounds__(128) void group_colsum_kernel(ReduceParams p) {
 }
 
 
-// Plain column sums of a NARROW contiguous matrix (ldx == D <= 1024 columns: the UNet's 320 / 640-channel activations, 163 840 rows).  The
+// Column sums (optionally also of x * y_normalised) of a NARROW matrix without row groups (<= 1024 columns, any row stride: the UNet's 320 / 640-channel activations, 163 840 rows).  The
 // general kernel above gives each thread 4 columns of a row: at 320 columns a block is 80 active lanes reading 8 bytes each, 0.76 TB/s.
 // Here a block of 256 threads is laid over whole rows -- thread = (row group, 16-byte chunk of the row), groups = 256 / (D / 8) rows side by side,
 // so a block reads one contiguous span per iteration (4 iterations in flight) --, the row groups are summed through LDS and one atomic per
 // column and block goes out.
-__global__ __launch_bounds__(256) void colsum_narrow_kernel(const bf16_t* __restrict__ X, long long M, int D, float* __restrict__ out, int rows_per_block) {
-    __shared__ float red[256 * 8];
+template <bool HASY>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, long long M, int D,
+                                                            float* __restrict__ out1, float* __restrict__ out2, int rows_per_block) {
+    __shared__ float red[(HASY ? 2 : 1) * 256 * 8];
     const int cpr = D >> 3;                       // 16-byte chunks per row
     const int groups = 256 / cpr;
     const int t = threadIdx.x;
     const int rg = t / cpr, cg = t - rg * cpr;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long long m0 = (long long)blockIdx.x * rows_per_block;
     const long long m1 = (m0 + rows_per_block) < M ? (m0 + rows_per_block) : M;
     if (rg < groups) {
         const bf16_t* px = X + (size_t)cg * 8;
+        const bf16_t* py = HASY ? Y + (size_t)cg * 8 : nullptr;
         for (long long m = m0 + rg; m < m1; m += 4 * groups) {
-            u32x4 v[4];
+            u32x4 v[4], w[4];
+            float mu[4], rs[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long mm = m + (long long)u * groups;
-                v[u] = (u32x4){0u, 0u, 0u, 0u};
-                if (mm < m1) v[u] = *(const u32x4*)(px + (size_t)mm * D);
+                v[u] = (u32x4){0u, 0u, 0u, 0u}; w[u] = v[u]; mu[u] = 0.f; rs[u] = 1.f;
+                if (mm < m1) {
+                    v[u] = *(const u32x4*)(px + (size_t)mm * ldx);
+                    if (HASY) {
+                        w[u] = *(const u32x4*)(py + (size_t)mm * ldy);
+                        if (mean != nullptr) { mu[u] = mean[mm]; rs[u] = rstd[mm]; }
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[2 * j] += __uint_as_float(v[u][j] << 16);
-                    acc[2 * j + 1] += __uint_as_float(v[u][j] & 0xffff0000u);
+                    const float x0 = __uint_as_float(v[u][j] << 16), x1 = __uint_as_float(v[u][j] & 0xffff0000u);
+                    acc[2 * j] += x0; acc[2 * j + 1] += x1;
+                    if (HASY) {                    // a row past the end contributes x = 0
+                        acc2[2 * j] += x0 * ((__uint_as_float(w[u][j] << 16) - mu[u]) * rs[u]);
+                        acc2[2 * j + 1] += x1 * ((__uint_as_float(w[u][j] & 0xffff0000u) - mu[u]) * rs[u]);
+                    }
                 }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[t * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) { red[t * 8 + j] = acc[j]; if (HASY) red[2048 + t * 8 + j] = acc2[j]; }
     __syncthreads();
     for (int c = t; c < D; c += 256) {            // column c lives in chunk c >> 3, element c & 7 of every row group
-        float sum = 0.f;
-        for (int g2 = 0; g2 < groups; ++g2) sum += red[(g2 * cpr + (c >> 3)) * 8 + (c & 7)];
-        atomicAdd(out + c, sum);
+        float sum = 0.f, sum2 = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) {
+            sum += red[(g2 * cpr + (c >> 3)) * 8 + (c & 7)];
+            if (HASY) sum2 += red[2048 + (g2 * cpr + (c >> 3)) * 8 + (c & 7)];
+        }
+        if (out1 != nullptr) atomicAdd(out1 + c, sum);
+        if (HASY && out2 != nullptr) atomicAdd(out2 + c, sum2);
     }
 }
 
@@ -133,11 +152,16 @@ extern "C" int vt_group_colsum(const void* X, int ldx, const void* Y, int ldy, c
     if (out2 != nullptr && Y == nullptr) return VT_ERR_BAD_SHAPE;
     if (grouped && (S <= 0 || St < 0 || St > S)) return VT_ERR_BAD_SHAPE;
     if ((((uintptr_t)X) | ((uintptr_t)Y)) & 7) return VT_ERR_BAD_ALIGN;
-    if (Y == nullptr && out2 == nullptr && mean == nullptr && !grouped && out1 != nullptr && ldx == D && (D % 8) == 0 && D <= 1024 && M >= 4096 &&
-        ((((uintptr_t)X) & 15) == 0)) {
+    if (!grouped && (D % 8) == 0 && D <= 1024 && M >= 4096 && (ldx % 8) == 0 && (Y == nullptr || (ldy % 8) == 0) &&
+        (((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0) && (mean == nullptr) == (rstd == nullptr) && (Y != nullptr || mean == nullptr)) {
         const int rows_per_block = 160;
-        const long long blocks = (M + rows_per_block - 1) / rows_per_block;
-        hipLaunchKernelGGL(colsum_narrow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, M, D, out1, rows_per_block);
+        const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+        if (Y != nullptr)
+            hipLaunchKernelGGL(colsum_narrow_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
+                               mean, rstd, M, D, out1, out2, rows_per_block);
+        else
+            hipLaunchKernelGGL(colsum_narrow_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)nullptr, 0,
+                               (const float*)nullptr, (const float*)nullptr, M, D, out1, (float*)nullptr, rows_per_block);
         return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
     }
     ReduceParams p{(const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, mean, rstd, out1, out2, M, D, S > 0 ? S : 1, St, grouped,

@@ -149,3 +149,46 @@ def test_tape_engine_exchange_world2_matches_unsharded():
         assert torch.allclose(tot, grads[3 + i], atol=1e-12), ("text operand", i)
         h = H // 2
         assert res[0][1][:, n:, i, h:].abs().max() == 0 and res[1][1][:, n:, i, :h].abs().max() == 0
+
+
+# ---- host-side geometry of the sequence-parallel HunyuanVideo denoiser (no kernels involved) ----
+def _worker_geometry(rank, world, port, res):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vt355.hunyuan import HYVideoDiffusionTransformer
+        m = HYVideoDiffusionTransformer(in_channels=4, hidden_size=256, heads_num=2, mm_double_blocks_depth=1, mm_single_blocks_depth=1,
+                                        text_states_dim=64, text_states_dim_2=32)
+        assert m._sp_rows(72) == (0, 72)                                  # no group: every row
+        m.set_sequence_parallel(dist.group.WORLD)
+        rows = m._sp_rows(72)
+        bad_rows = None
+        try:
+            m._sp_rows(73)
+        except ValueError as e:
+            bad_rows = str(e)
+        m3 = HYVideoDiffusionTransformer(in_channels=4, hidden_size=384, heads_num=3, mm_double_blocks_depth=1, mm_single_blocks_depth=1,
+                                         text_states_dim=64, text_states_dim_2=32)
+        bad_heads = None
+        try:
+            m3.set_sequence_parallel(dist.group.WORLD)
+        except ValueError as e:
+            bad_heads = str(e)
+        x = torch.arange(2 * 4 * 3 * 8 * 12, dtype=torch.float32).view(2, 4, 3, 8, 12)
+        tok = m.patchify(x)                                                # [B, N, C pt ph pw], token order (t, h, w), columns (c, pt, ph, pw)
+        back = tok.view(2, 3, 4, 6, 4, 1, 2, 2).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(2, 4, 3, 8, 12)      # the final layer's unpatchify
+        res[rank] = (rows, bad_rows, bad_heads, tuple(tok.shape), bool(torch.equal(back, x)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_parallel_geometry_of_the_hunyuan_denoiser():
+    mgr = mp.Manager(); res = mgr.dict()
+    mp.spawn(_worker_geometry, args=(2, _free_port(), res), nprocs=2, join=True)
+    for r in (0, 1):
+        rows, bad_rows, bad_heads, shape, roundtrip = res[r]
+        assert rows == (36 * r, 36)
+        assert bad_rows is not None and "do not split" in bad_rows
+        assert bad_heads is not None and "do not split" in bad_heads
+        assert shape == (2, 72, 16) and roundtrip

@@ -1893,12 +1893,14 @@ static long long bwd_chain_xcc_off(long long slots) { return 256 + slots * 64; }
 static long long bwd_chain_tiles_off(long long slots) { return (256 + slots * 68 + 4095) & ~4095LL; }
 static long long bwd_chain_ws_bytes(long long slots) { return bwd_chain_tiles_off(slots) + slots * (long long)(CH_R * 16384); }
 static int g_bwd_slots = 0;      // persistent grid: one workgroup per CU, a multiple of 8
-// chain length: VT_BWD_CHAIN (1 = off), default 2 (measured best: see the header comment).  The persistent grid is one workgroup per CU (the kernel's 145 KiB
+// chain length: VT_BWD_CHAIN (1 = off), default 3.  (r01 .. mid-r02: 2 was measured best, 3 / 4 were 2-3 % slower.  With the 16x16x32 S phase and the
+// conflict-free dS image, same box: B=1 loop 6.61-6.64 ms at 3 against 6.65-6.68 at 2 and 6.75-6.80 at 4; inside the training step 23.5-23.9 against
+// 23.9 ms per B=4 launch -- equal or better, with a third fewer dQ atomics.)  The persistent grid is one workgroup per CU (the kernel's 145 KiB
 // of LDS allow exactly one), so every slot is resident and chain neighbours start together.
 static int g_bwd_chain = -1;
 static void bwd_chain_init() {
     if (g_bwd_chain >= 0) return;
-    int L = 2;
+    int L = 3;
     if (const char* e = getenv("VT_BWD_CHAIN")) L = atoi(e);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;

@@ -174,7 +174,7 @@ int vt_attn_bwd_hd64(const void* q, const void* k, const void* v, const void* o,
                      long long dq_bs, long long dk_bs, long long dv_bs,
                      float softmax_scale, int q_prescaled, void* chain_ws, long long chain_ws_bytes, void* stream);
 long long vt_attn_bwd_chain_ws_bytes(int B, int H, int S);
-/* tuning / test knob: chain_len 1 = atomics only, 0 = default (8, or VT_BWD_CHAIN); slots 0 = one workgroup per CU,
+/* tuning / test knob: chain_len 1 = atomics only, 0 = default (3, or VT_BWD_CHAIN); slots 0 = one workgroup per CU,
  * else a smaller persistent grid (multiple of 8) so that small problems run several generations */
 int vt_attn_bwd_set_chain(int chain_len, int slots);
 
